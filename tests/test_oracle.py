@@ -1,0 +1,82 @@
+"""The CPU oracle against the golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sc_oracle as orc
+from tests import cases
+
+torch.set_default_dtype(torch.float64)
+
+TOL = 1e-11
+
+
+@pytest.mark.parametrize("name", cases.HK_CASES + cases.WM_CASES)
+def test_oracle_matches_reference(name):
+    g = cases.load(name)
+    pot = cases.oracle_potential(g)
+    prop = cases.oracle_propagator(g)
+    nt, dt, E0 = int(g["nt"]), float(g["dt"]), float(g["E0"])
+    is_wm = "alpha" in g
+    assert cases.rel_err(prop.U.numpy(), g["U"]) < 1e-14
+    assert cases.rel_err(prop.iGi0.numpy(), g["iGi0"]) < 1e-13
+    cauto = np.zeros(nt, dtype=complex)
+    kic = np.zeros(nt, dtype=complex)
+    for t in range(nt):
+        assert cases.rel_err(prop.c2.numpy(), g["c2"][t]) < TOL
+        cauto[t] = prop.autocorrelation(E0)
+        kic[t] = prop.ic_correlation(pot, E0)
+        prop.step(pot, dt)
+        step = t + 1
+        if step in g["snaps"]:
+            if f"y_{step}" in g:
+                assert cases.rel_err(prop.y.numpy(), g[f"y_{step}"]) < TOL
+            else:
+                assert cases.rel_err(prop.y[:, 0].numpy(), g[f"ytraj0_{step}"]) < TOL
+            assert np.array_equal(prop.tracker.signs("prefactorC").numpy(), g[f"signs_{step}"])
+            assert cases.rel_err(prop.autocorrelation_qp().numpy(), g[f"cauto_qp_{step}"]) < 1e-10
+            if is_wm:
+                assert np.array_equal(prop.tracker.signs("detA").numpy(), g[f"signsA_{step}"])
+                assert np.array_equal(prop.tracker.signs("detM").numpy(), g[f"signsM_{step}"])
+                assert cases.rel_err(prop.gamma.numpy(), g[f"gamma_{step}"]) < 1e-10
+    assert cases.rel_err(cauto, g["cauto"]) < TOL
+    assert cases.rel_err(kic, g["kic"]) < 1e-10
+
+
+def test_seeded_sampling_reproduces_reference():
+    """initial_conditions() under manual_seed(0) draws the reference's zi/probi (same torch CPU RNG)."""
+    g = cases.load("hk_as5_chi002")
+    prop = orc.HKOracle(cases.T(g["Gamma_i"]), cases.T(g["Gamma_t"]))
+    torch.manual_seed(0)
+    prop.initial_conditions(cases.T(g["q0"]), cases.T(g["p0"]), cases.T(g["Gamma_0"]), ntraj=g["zi"].shape[1])
+    if abs(prop.zi[0, 0].item() - g["zi"][0, 0]) > 1e-9:
+        pytest.skip("torch CPU normal stream differs on this host")
+    assert cases.rel_err(prop.zi.numpy(), g["zi"]) < 1e-14
+    assert cases.rel_err(prop.probi.numpy(), g["probi"]) < 1e-13
+
+
+def test_overlap_normalisation_and_zero_modes():
+    """reference tests/test_propagators.py:73-113"""
+    torch.manual_seed(0)
+    n = 5
+    Gi = 5.0 * 2.0 * (torch.rand(n, n) - 0.5)
+    Gi = 0.5 * (Gi + Gi.T)
+    qi, pi = torch.rand(n, 1), torch.rand(n, 1)
+    olap = orc.OverlapOracle(Gi, Gi)(qi, pi, qi, pi).squeeze().item()
+    assert abs(olap - 1.0) < 1e-5
+    Gi_ = torch.zeros((n + 1, n + 1))
+    Gi_[:n, :n] = Gi
+    qi_, pi_ = (torch.cat((x, torch.zeros(1, 1)), 0) for x in (qi, pi))
+    olap_ = orc.OverlapOracle(Gi_, Gi_)(qi_, pi_, qi_, pi_).squeeze().item()
+    assert olap == olap_
+
+
+def test_sym_sqrtm():
+    """reference tests/test_propagators.py:40-54"""
+    import scipy.linalg as sla
+    torch.manual_seed(0)
+    A = 5.0 * 2.0 * (torch.rand(5, 5) - 0.5)
+    A = A + A.T
+    s, i = orc.sym_sqrtm(A)
+    assert np.allclose(s.numpy(), sla.sqrtm(A.numpy()))
+    assert np.allclose(i.numpy(), sla.inv(sla.sqrtm(A.numpy())))
