@@ -1,0 +1,153 @@
+/*
+ * semiclassical_hip.h -- C-ABI of the MI355X (gfx950) trajectory engine.
+ *
+ * The reference (humeniuka/semiclassical) has no FFI boundary: its hot path is a
+ * sequence of eager PyTorch ops inside two Python classes.  This header is the
+ * boundary the build introduces underneath those classes: every entry point
+ * replaces one group of reference ops (cited per function, paths relative to the
+ * reference repository).  The Python classes in semiclassical_amd/propagators.py
+ * bind these symbols with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - all pointers inside the structs are DEVICE pointers (torch owns every
+ *     buffer; nothing is allocated, freed or retained by the library);
+ *   - fp64 everywhere; complex numbers are interleaved (re, im) doubles;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - every function returns 0 on success or a negative SC_ERR_* code and never
+ *     synchronises the device; sc_last_error() gives the message of the last
+ *     failure on the calling thread.
+ *
+ * Engine-native state layout ("trajectory-major"):
+ *     qp   [n][2*D]        q(0..D-1), p(0..D-1) of one trajectory are contiguous
+ *     act  [n]             classical action S
+ *     mono [n][4][D][D]    monodromy blocks Mqq, Mqp, Mpq, Mpp (row-major a,b)
+ *     c2   [n] complex     HK prefactor squared  (the sign tracker's "previous")
+ *     sgn  [n]             accumulated branch sign (+1/-1) of sqrt(c2)
+ * The reference's (rows, n) tensor `y` is produced from / converted to this
+ * layout by sc_state_from_reference / sc_state_to_reference.
+ */
+#ifndef SEMICLASSICAL_HIP_H
+#define SEMICLASSICAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_OK                 0
+#define SC_ERR_BAD_ARGUMENT  -1
+#define SC_ERR_UNSUPPORTED   -2   /* shape outside what the kernels hold on chip */
+#define SC_ERR_LAUNCH        -3   /* hip launch / runtime error */
+
+/* potential kinds: reference semiclassical/potentials.py */
+#define SC_POT_MORSE          1   /* MorsePotential, chi != 0           potentials.py:274-327 */
+#define SC_POT_HARMONIC_SEP   2   /* MorsePotential, all chi == 0       potentials.py:267-312 */
+#define SC_POT_EPS_MORSE      3   /* NonHarmonicPotential               potentials.py:63-134  */
+#define SC_POT_HARMONIC_DENSE 4   /* MolecularHarmonicPotential         potentials.py:553-593 */
+
+typedef struct sc_potential {
+    int32_t kind;           /* SC_POT_* */
+    int32_t dim;            /* D */
+    const double *par0;     /* MORSE: a[D]  HARMONIC_SEP: omega^2[D]  EPS_MORSE: eps[D]  DENSE: pos0[D]      */
+    const double *par1;     /* MORSE: De[D]                            EPS_MORSE: b[D]    DENSE: grad0[D]     */
+    const double *par2;     /*                                                            DENSE: hess0[D][D]  */
+    double        scalar0;  /*                                                            DENSE: energy0 - origin */
+    const double *inv_mass; /* 1/m [D]                                 potentials.py:261-263, 549 */
+} sc_potential;
+
+typedef struct sc_state {
+    int64_t n;              /* trajectories in this batch (this rank's shard) */
+    int32_t dim;            /* D */
+    int32_t _pad;
+    double *qp;
+    double *act;
+    double *mono;
+    double *c2;
+    double *sgn;
+} sc_state;
+
+/* constants of the HK prefactor, reference propagators.py:951-1004.
+ * diag != 0: Gamma_i, Gamma_t diagonal and of full rank; st = sqrt(diag Gamma_t),
+ *            si = sqrt(diag Gamma_i).
+ * diag == 0: L1 = U^T Gt^{1/2}, L2 = U^T Gt^{-1/2} (d' x D complex),
+ *            R1 = Gi^{-1/2} U,  R2 = Gi^{1/2} U   (D x d' complex). */
+typedef struct sc_hk_consts {
+    int32_t dim, dprime, diag, _pad;
+    const double *st, *si;
+    const double *L1, *L2, *R1, *R2;
+} sc_hk_consts;
+
+/* constants of <q,p,G_bra | qk,pk,G_ket>, reference propagators.py:124-240.
+ * diag != 0: A, B, C hold D diagonal entries, else D x D row-major.
+ *   A = Gbra.iG.Gket   B = iG = (Gbra+Gket)^+   C = Gket.iG   fac = sqrt(2^rank sqrt(detGbra detGket)/detG) */
+typedef struct sc_overlap_consts {
+    int32_t dim, diag;
+    const double *A, *B, *C;
+    const double *qk, *pk;  /* centre of the ket, [D] each */
+    double fac;
+} sc_overlap_consts;
+
+/* constants of the non-adiabatic coupling factors, reference propagators.py:886-903
+ *   n1 = -hbar^2 nac/m ;  rn = R.n1 with R = G0.iGi0.Gi ;  gn = (G0.iGi0)^T.n1 ;
+ *   p0n1 = p0.n1 ;  n2 = -hbar^2/2 sum_k tau2_k/m_k (0 for every reference potential) */
+typedef struct sc_nac_consts {
+    int32_t dim, _pad;
+    const double *rn, *gn;
+    const double *q0, *p0;
+    double p0n1, n2;
+} sc_nac_consts;
+
+int         sc_version(void);
+const char *sc_last_error(void);
+
+/* number of workgroups sc_hk_step / sc_hk_correlate use for n trajectories of dimension D;
+ * the caller sizes the `partials` buffers with it. */
+int sc_step_grid(int64_t n, int32_t dim);
+int sc_correlate_grid(int64_t n, int32_t dim);
+
+/* y (rows = 2D+4D^2+1, n) with n fastest  <->  engine layout.   reference propagators.py:329-334, 581 */
+int sc_state_from_reference(const double *y, const sc_state *st, void *stream);
+int sc_state_to_reference(const sc_state *st, double *y, void *stream);
+
+/* One RK4 step of (q,p,Mqq,Mqp,Mpq,Mpp,S) followed by the HK prefactor and its sqrt-branch tracking,
+ * fused per trajectory.  Replaces _rk4_step + EquationsOfMotion.f + potential.harmonic_approximation
+ * (propagators.py:86-119, 313-383) and _prefactor + _track_signs_of_sqrt (propagators.py:951-1052).
+ *   energy_partials[sc_step_grid()]: per-workgroup sums of T+V at the k4 stage (propagators.py:380).
+ *   mode 0: step + prefactor;  mode 1: prefactor only with tracker initialisation (t = 0, propagators.py:631). */
+int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk,
+               double dt, int32_t mode, double *energy_partials, void *stream);
+
+/* out[i] = <qp[i] , G_bra | qk,pk,G_ket> for i < n  (complex).  propagators.py:181-240 with a single ket. */
+int sc_overlap(const sc_overlap_consts *oc, const double *qp, int64_t n, double *out, void *stream);
+
+/* nac factor of the INITIAL points: nacq = n2 + (q0-q).rn + i/hbar (p0n1 + (p-p0).gn).  propagators.py:902-903 */
+int sc_nac_initial(const sc_nac_consts *nc, const double *zi, int64_t n, double *nacq, void *stream);
+
+/* Per-trajectory terms of C_auto and k_ic for the current state and their per-workgroup partial sums.
+ * Replaces autocorrelation_qp / autocorrelation / ic_correlation (propagators.py:784-911) up to the
+ * phase exp(i t E0/hbar), which the host applies.
+ *   w_i      = 1 / (mc_norm * probi_i),  mc_norm = N_total (2 pi hbar)^D      propagators.py:837
+ *   cq_i     = conj(vt_i) vi_i sgn_i sqrt(c2_i) exp(i S_i/hbar) w_i           propagators.py:806
+ *   kq_i     = nacQ_i nacq_i cq_i / hbar^2  (skipped when nc == NULL)         propagators.py:900-909
+ *   partials[sc_correlate_grid()][4] = sums of (cq.re, cq.im, kq.re, kq.im) per workgroup
+ *   cq_out / kq_out (complex [n]) may be NULL. */
+int sc_hk_correlate(const sc_state *st, const sc_overlap_consts *ovl_t0, const sc_nac_consts *nc,
+                    const double *vi, const double *probi, const double *nacq, double mc_norm,
+                    double *cq_out, double *kq_out, double *partials, void *stream);
+
+/* slot[0..3] = sum of correlate partials, slot[4] = (sum of energy partials)/n_energy.
+ * Deterministic (fixed summation order).  Either partial buffer may be NULL (its slots are left untouched). */
+int sc_reduce_slot(const double *corr_partials, int32_t n_corr, const double *energy_partials, int32_t n_energy_blocks,
+                   double n_energy, double *slot, void *stream);
+
+/* Energy-conservation guard on the device, reference propagators.py:385-398 (check_energy_conservation).
+ * elog[4] = { <T+V>(t-dt), <T+V>(t), largest |change| seen so far, number of steps logged }.
+ * The mean of this step is formed from energy_partials; the host raises the reference's RuntimeError when
+ * elog[2] > 1e-2 Hartree the next time it synchronises. */
+int sc_energy_guard(const double *energy_partials, int32_t n_blocks, double n_traj, double *elog, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMICLASSICAL_HIP_H */

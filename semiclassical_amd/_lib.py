@@ -1,0 +1,94 @@
+"""ctypes binding of libsemiclassical_hip.so (declared in include/semiclassical_hip.h).
+
+There is no fallback: if the shared library is missing or a symbol cannot be
+resolved the import fails loudly -- the engine has no CPU path.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsemiclassical_hip.so")
+
+c_double_p = C.c_void_p      # device pointers travel as plain integers
+
+
+class sc_potential(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dim", C.c_int32),
+                ("par0", c_double_p), ("par1", c_double_p), ("par2", c_double_p),
+                ("scalar0", C.c_double), ("inv_mass", c_double_p)]
+
+
+class sc_state(C.Structure):
+    _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("_pad", C.c_int32),
+                ("qp", c_double_p), ("act", c_double_p), ("mono", c_double_p),
+                ("c2", c_double_p), ("sgn", c_double_p)]
+
+
+class sc_hk_consts(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("dprime", C.c_int32), ("diag", C.c_int32), ("_pad", C.c_int32),
+                ("st", c_double_p), ("si", c_double_p),
+                ("L1", c_double_p), ("L2", c_double_p), ("R1", c_double_p), ("R2", c_double_p)]
+
+
+class sc_overlap_consts(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("diag", C.c_int32),
+                ("A", c_double_p), ("B", c_double_p), ("C", c_double_p),
+                ("qk", c_double_p), ("pk", c_double_p), ("fac", C.c_double)]
+
+
+class sc_nac_consts(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("_pad", C.c_int32),
+                ("rn", c_double_p), ("gn", c_double_p), ("q0", c_double_p), ("p0", c_double_p),
+                ("p0n1", C.c_double), ("n2", C.c_double)]
+
+
+SC_POT_MORSE, SC_POT_HARMONIC_SEP, SC_POT_EPS_MORSE, SC_POT_HARMONIC_DENSE = 1, 2, 3, 4
+
+# every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
+P = C.POINTER
+SIGNATURES = {
+    "sc_version": (C.c_int, []),
+    "sc_last_error": (C.c_char_p, []),
+    "sc_step_grid": (C.c_int, [C.c_int64, C.c_int32]),
+    "sc_correlate_grid": (C.c_int, [C.c_int64, C.c_int32]),
+    "sc_state_from_reference": (C.c_int, [c_double_p, P(sc_state), C.c_void_p]),
+    "sc_state_to_reference": (C.c_int, [P(sc_state), c_double_p, C.c_void_p]),
+    "sc_hk_step": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), C.c_double, C.c_int32,
+                             c_double_p, C.c_void_p]),
+    "sc_overlap": (C.c_int, [P(sc_overlap_consts), c_double_p, C.c_int64, c_double_p, C.c_void_p]),
+    "sc_nac_initial": (C.c_int, [P(sc_nac_consts), c_double_p, C.c_int64, c_double_p, C.c_void_p]),
+    "sc_hk_correlate": (C.c_int, [P(sc_state), P(sc_overlap_consts), P(sc_nac_consts), c_double_p, c_double_p,
+                                  c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, C.c_void_p]),
+    "sc_energy_guard": (C.c_int, [c_double_p, C.c_int32, C.c_double, c_double_p, C.c_void_p]),
+    "sc_reduce_slot": (C.c_int, [c_double_p, C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p,
+                                 C.c_void_p]),
+}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m semiclassical_amd.build` "
+            "(hipcc --offload-arch=gfx950).  semiclassical_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise EngineError(f"semiclassical_hip error {rc}: {lib.sc_last_error().decode()}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or NULL)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

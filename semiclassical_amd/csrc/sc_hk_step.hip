@@ -1,0 +1,388 @@
+// Fused Herman-Kluk step: RK4 of (q, p, S, monodromy) + HK prefactor + sqrt branch tracking.
+//
+// One workgroup owns one trajectory at a time (grid-stride over trajectories).  The trajectory's
+// four D x D monodromy blocks are contiguous in HBM (engine layout, include/semiclassical_hip.h),
+// so every load/store below is a unit-stride sweep.
+//
+// Reference semantics reproduced (paths relative to the reference repository):
+//   RK4 stage formula                       semiclassical/propagators.py:86-119
+//   slopes of q, p, Mqq, Mqp, Mpq, Mpp, S   semiclassical/propagators.py:313-383
+//   mean of T+V at the k4 stage             semiclassical/propagators.py:380   (quirk Q2)
+//   potentials                              semiclassical/potentials.py:63-134, 265-327, 553-593
+//   HK prefactor, eqn (29)                  semiclassical/propagators.py:951-1004
+//   branch tracking of sqrt(c2)             semiclassical/propagators.py:1006-1052
+#include "sc_common.h"
+
+namespace {
+
+struct StepArgs {
+    sc_potential pot;
+    sc_state st;
+    sc_hk_consts hk;
+    double dt;
+    int mode;
+    double *epart;
+};
+
+// V, dV/dx, d2V/dx2 of one mode of a separable potential
+__device__ __forceinline__ void sep_eval(int kind, double c0, double c1, double x, double &v, double &g, double &h) {
+    if (kind == SC_POT_MORSE) {                    // c0 = a, c1 = De
+        double e = exp(-c0 * x);
+        double om = 1.0 - e;
+        v = c1 * om * om;
+        g = 2.0 * c0 * c1 * e * om;
+        h = 2.0 * c0 * c0 * c1 * e * (2.0 * e - 1.0);
+    } else if (kind == SC_POT_HARMONIC_SEP) {      // c0 = omega^2
+        v = 0.5 * c0 * x * x;
+        g = c0 * x;
+        h = c0;
+    } else {                                       // SC_POT_EPS_MORSE: c0 = eps, c1 = b
+        double e1 = exp(-c1 * x), e2 = exp(-2.0 * c1 * x);
+        double om = 1.0 - e1;
+        v = c0 / (2.0 * c1 * c1) * om * om + (1.0 - c0) * 0.5 * x * x;
+        g = c0 / c1 * (e1 - e2) + (1.0 - c0) * x;
+        h = c0 * (2.0 * e2 - e1) + (1.0 - c0);
+    }
+}
+
+// RK4 of the pair (u, v) with du/dt = v/m, dv/dt = -h(t) u  (diagonal Hessian)
+__device__ __forceinline__ void rk4_pair(double &u, double &v, double im, double h1, double h2, double h3, double h4,
+                                         double dt) {
+    const double hh = 0.5 * dt, h6 = dt / 6.0;
+    double k1u = v * im, k1v = -h1 * u;
+    double u2 = u + hh * k1u, v2 = v + hh * k1v;
+    double k2u = v2 * im, k2v = -h2 * u2;
+    double u3 = u + hh * k2u, v3 = v + hh * k2v;
+    double k3u = v3 * im, k3v = -h3 * u3;
+    double u4 = u + dt * k3u, v4 = v + dt * k3v;
+    double k4u = v4 * im, k4v = -h4 * u4;
+    u = u + h6 * (k1u + 2.0 * k2u + 2.0 * k3u + k4u);
+    v = v + h6 * (k1v + 2.0 * k2v + 2.0 * k3v + k4v);
+}
+
+// det of the d x d complex matrix A (LDS, row-major), LU with partial pivoting; A is destroyed.
+// Every thread returns the determinant.  `ipiv` is one LDS int.
+__device__ cplx lds_lu_det(cplx *A, int d, int *ipiv) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    cplx det = c_make(1.0, 0.0);
+    for (int k = 0; k < d; ++k) {
+        if (wave == 0) {
+            double best = -1.0;
+            int bi = k;
+            for (int i = k + lane; i < d; i += 64) {
+                double m = c_abs2(A[i * d + k]);
+                if (m > best) { best = m; bi = i; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                double ob = __shfl_xor(best, off, 64);
+                int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (bi != k) {
+                for (int j = k + lane; j < d; j += 64) {
+                    cplx t = A[k * d + j];
+                    A[k * d + j] = A[bi * d + j];
+                    A[bi * d + j] = t;
+                }
+            }
+            if (lane == 0) *ipiv = bi;
+        }
+        __syncthreads();
+        const cplx piv = A[k * d + k];
+        det = c_mul(det, piv);
+        if (*ipiv != k) det = c_make(-det.x, -det.y);
+        if (piv.x == 0.0 && piv.y == 0.0) {        // singular: uniform exit
+            __syncthreads();
+            return c_make(0.0, 0.0);
+        }
+        const cplx inv = c_inv(piv);
+        for (int i = k + 1 + wave; i < d; i += nw) {
+            const cplx l = c_mul(A[i * d + k], inv);
+            for (int j = k + 1 + lane; j < d; j += 64) A[i * d + j] = c_fnma(l, A[k * d + j], A[i * d + j]);
+        }
+        __syncthreads();
+    }
+    return det;
+}
+
+// General (dense Gamma / rank-deficient) prefactor matrix
+//   mat' = 1/2 [ L1 (Mqq R1 - i hbar Mqp R2) + L2 (Mpp R2 + i/hbar Mpq R1) ]       (d' x d')
+// M planes are read through generic pointers (global or LDS), leading dimension ldm, plane offsets given.
+__device__ void general_prefactor_matrix(const sc_hk_consts &hk, const double *Mqq, const double *Mqp,
+                                         const double *Mpq, const double *Mpp, int ldm, cplx *X, cplx *mat) {
+    const int D = hk.dim, dp = hk.dprime, tid = threadIdx.x, nth = blockDim.x;
+    const cplx *L1 = (const cplx *)hk.L1, *L2 = (const cplx *)hk.L2;
+    const cplx *R1 = (const cplx *)hk.R1, *R2 = (const cplx *)hk.R2;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double *Ma = pass == 0 ? Mqq : Mpp, *Mb = pass == 0 ? Mqp : Mpq;
+        const cplx *Ra = pass == 0 ? R1 : R2, *Rb = pass == 0 ? R2 : R1;
+        const cplx fb = pass == 0 ? c_make(0.0, -SC_HBAR) : c_make(0.0, 1.0 / SC_HBAR);
+        const cplx *L = pass == 0 ? L1 : L2;
+        for (int e = tid; e < D * dp; e += nth) {
+            const int a = e / dp, j = e - a * dp;
+            cplx s1 = c_make(0, 0), s2 = c_make(0, 0);
+            for (int b = 0; b < D; ++b) {
+                const double ma = Ma[a * ldm + b], mb = Mb[a * ldm + b];
+                const cplx ra = Ra[b * dp + j], rb = Rb[b * dp + j];
+                s1.x = fma(ma, ra.x, s1.x); s1.y = fma(ma, ra.y, s1.y);
+                s2.x = fma(mb, rb.x, s2.x); s2.y = fma(mb, rb.y, s2.y);
+            }
+            X[e] = c_add(s1, c_mul(fb, s2));
+        }
+        __syncthreads();
+        for (int e = tid; e < dp * dp; e += nth) {
+            const int i = e / dp, j = e - i * dp;
+            cplx s = c_make(0, 0);
+            for (int a = 0; a < D; ++a) s = c_fma(L[i * D + a], X[a * dp + j], s);
+            s = c_scale(s, 0.5);
+            mat[e] = pass == 0 ? s : c_add(mat[e], s);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ size_t align2(size_t x) { return (x + 1) & ~size_t(1); }
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
+    extern __shared__ double2 smem2[];
+    double *smem = (double *)smem2;
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x, nth = blockDim.x;
+    const int dp = A.hk.dprime;
+    const bool diag = A.hk.diag != 0;
+    const bool do_step = A.mode == 0;
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+
+    // ---- LDS carve-up (all offsets even => 16-byte aligned) ----
+    size_t off = 0;
+    double *red = smem + off;  off += 32;
+    int *ipiv = (int *)(smem + off); off += 2;
+    double *hst = smem + off;  off += align2(4 * D);     // stage Hessian diagonals (separable)
+    double *vec = smem + off;  off += align2(4 * D);     // st, 1/st, si, 1/si (diag prefactor)
+    cplx *mat = (cplx *)(smem + off); off += 2 * (size_t)dp * dp;
+    cplx *X = (cplx *)(smem + off);
+    if (!diag) off += 2 * (size_t)D * dp;
+    // dense potential: Mq, Mp, Aq, Ap, Qa, Qb, Ps (each D x 2D), hess (D x D), dr (D)
+    double *Mq = smem + off, *Mp = Mq + 2 * DD, *Aq = Mp + 2 * DD, *Ap = Aq + 2 * DD;
+    double *Qa = Ap + 2 * DD, *Qb = Qa + 2 * DD, *Ps = Qb + 2 * DD;
+    double *Hm = Ps + 2 * DD, *drv = Hm + DD;
+
+    if (diag) {
+        for (int a = tid; a < D; a += nth) {
+            vec[a] = A.hk.st[a]; vec[D + a] = 1.0 / A.hk.st[a];
+            vec[2 * D + a] = A.hk.si[a]; vec[3 * D + a] = 1.0 / A.hk.si[a];
+        }
+    }
+    if (DENSE) {
+        for (int e = tid; e < DD; e += nth) Hm[e] = A.pot.par2[e];
+    }
+    __syncthreads();
+
+    double esum = 0.0;
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        double *qp = A.st.qp + tr * 2 * D;
+        double *M = A.st.mono + tr * 4 * (int64_t)DD;
+        double im = 1.0;
+
+        if (do_step) {
+            // ---------------- phase A: classical trajectory (q, p, S) ----------------
+            double red5[5] = {0, 0, 0, 0, 0};
+            double qn = 0, pn = 0;
+            const bool own = tid < D;
+            double q = 0, p = 0;
+            if (own) { q = qp[tid]; p = qp[D + tid]; im = A.pot.inv_mass[tid]; }
+            if (!DENSE) {
+                if (own) {
+                    const double c0 = A.pot.par0[tid], c1 = A.pot.par1 ? A.pot.par1[tid] : 0.0;
+                    double v, g, h;
+                    sep_eval(A.pot.kind, c0, c1, q, v, g, h);
+                    const double kq1 = p * im, kp1 = -g; hst[tid] = h;
+                    red5[0] = 0.5 * p * p * im - v;
+                    const double q2 = q + hh * kq1, p2 = p + hh * kp1;
+                    sep_eval(A.pot.kind, c0, c1, q2, v, g, h);
+                    const double kq2 = p2 * im, kp2 = -g; hst[D + tid] = h;
+                    red5[1] = 0.5 * p2 * p2 * im - v;
+                    const double q3 = q + hh * kq2, p3 = p + hh * kp2;
+                    sep_eval(A.pot.kind, c0, c1, q3, v, g, h);
+                    const double kq3 = p3 * im, kp3 = -g; hst[2 * D + tid] = h;
+                    red5[2] = 0.5 * p3 * p3 * im - v;
+                    const double q4 = q + dt * kq3, p4 = p + dt * kp3;
+                    sep_eval(A.pot.kind, c0, c1, q4, v, g, h);
+                    const double kq4 = p4 * im, kp4 = -g; hst[3 * D + tid] = h;
+                    red5[3] = 0.5 * p4 * p4 * im - v;
+                    red5[4] = 0.5 * p4 * p4 * im + v;
+                    qn = q + h6 * (kq1 + 2.0 * kq2 + 2.0 * kq3 + kq4);
+                    pn = p + h6 * (kp1 + 2.0 * kp2 + 2.0 * kp3 + kp4);
+                }
+            } else {
+                // V = E0 + g.dr + 1/2 dr.H.dr - origin ; grad = g + H.dr      potentials.py:583-590
+                double qs = q, ps = p, kqs = 0, kps = 0;
+                const double g0 = own ? A.pot.par1[tid] : 0.0, x0 = own ? A.pot.par0[tid] : 0.0;
+                for (int s = 0; s < 4; ++s) {
+                    if (s > 0) { const double c = (s == 3) ? dt : hh; qs = q + c * kqs; ps = p + c * kps; }
+                    __syncthreads();
+                    if (own) drv[tid] = qs - x0;
+                    __syncthreads();
+                    double kq = 0, kp = 0;
+                    if (own) {
+                        double hd = 0.0;
+                        for (int b = 0; b < D; ++b) hd = fma(Hm[tid * D + b], drv[b], hd);
+                        const double dr = qs - x0;
+                        const double v = dr * g0 + 0.5 * dr * hd;   // + scalar0 added after the reduction
+                        kq = ps * im; kp = -(g0 + hd);
+                        const double t = 0.5 * ps * ps * im;
+                        red5[s] = t - v;
+                        if (s == 3) red5[4] = t + v;
+                        const double w = (s == 0 || s == 3) ? 1.0 : 2.0;
+                        qn += w * kq; pn += w * kp;
+                    }
+                    kqs = kq; kps = kp;
+                }
+                if (own) { qn = q + h6 * qn; pn = p + h6 * pn; }
+            }
+            block_sum<5>(red5, red);
+            if (DENSE) {
+                for (int s = 0; s < 4; ++s) red5[s] -= A.pot.scalar0;
+                red5[4] += A.pot.scalar0;
+            }
+            if (own) { qp[tid] = qn; qp[D + tid] = pn; }
+            if (tid == 0) {
+                A.st.act[tr] += h6 * (red5[0] + 2.0 * red5[1] + 2.0 * red5[2] + red5[3]);
+                esum += red5[4];
+            }
+            __syncthreads();   // hst visible
+        }
+
+        // ---------------- phase B: monodromy blocks ----------------
+        if (!DENSE) {
+            for (int e = tid; e < DD; e += nth) {
+                const int a = e / D, b = e - a * D;
+                double mqq = M[e], mqp = M[DD + e], mpq = M[2 * DD + e], mpp = M[3 * DD + e];
+                if (do_step) {
+                    const double ima = A.pot.inv_mass[a];
+                    const double h1 = hst[a], h2 = hst[D + a], h3 = hst[2 * D + a], h4 = hst[3 * D + a];
+                    rk4_pair(mqq, mpq, ima, h1, h2, h3, h4, dt);
+                    rk4_pair(mqp, mpp, ima, h1, h2, h3, h4, dt);
+                    M[e] = mqq; M[DD + e] = mqp; M[2 * DD + e] = mpq; M[3 * DD + e] = mpp;
+                }
+                if (diag) {
+                    const double sta = vec[a], ista = vec[D + a], sib = vec[2 * D + b], isib = vec[3 * D + b];
+                    mat[e] = c_make(0.5 * (sta * isib * mqq + ista * sib * mpp),
+                                    0.5 * (-SC_HBAR * sta * sib * mqp + (1.0 / SC_HBAR) * ista * isib * mpq));
+                }
+            }
+            __syncthreads();
+            if (!diag) general_prefactor_matrix(A.hk, M, M + DD, M + 2 * DD, M + 3 * DD, D, X, mat);
+        } else {
+            const int W = 2 * D;
+            for (int e = tid; e < DD; e += nth) {
+                const int a = e / D, b = e - a * D;
+                Mq[a * W + b] = M[e]; Mq[a * W + D + b] = M[DD + e];
+                Mp[a * W + b] = M[2 * DD + e]; Mp[a * W + D + b] = M[3 * DD + e];
+            }
+            __syncthreads();
+            if (do_step) {
+                const double *Qc = Mq;
+                double *Qn = Qa;
+                for (int s = 0; s < 4; ++s) {
+                    const double w = (s == 0 || s == 3) ? 1.0 : 2.0;
+                    const double c = (s == 2) ? dt : hh;
+                    for (int e = tid; e < 2 * DD; e += nth) {
+                        const int a = e / W, col = e - a * W;
+                        const double pc = (s == 0) ? Mp[e] : Ps[e];
+                        const double kq = pc * A.pot.inv_mass[a];
+                        double hq = 0.0;
+                        for (int g = 0; g < D; ++g) hq = fma(Hm[a * D + g], Qc[g * W + col], hq);
+                        const double kp = -hq;
+                        if (s == 0) { Aq[e] = kq; Ap[e] = kp; } else { Aq[e] += w * kq; Ap[e] += w * kp; }
+                        if (s < 3) { Qn[e] = Mq[e] + c * kq; Ps[e] = Mp[e] + c * kp; }
+                    }
+                    __syncthreads();
+                    Qc = Qn;
+                    Qn = (Qn == Qa) ? Qb : Qa;
+                }
+                for (int e = tid; e < 2 * DD; e += nth) {
+                    Mq[e] = Mq[e] + h6 * Aq[e];
+                    Mp[e] = Mp[e] + h6 * Ap[e];
+                }
+                __syncthreads();
+                for (int e = tid; e < DD; e += nth) {
+                    const int a = e / D, b = e - a * D;
+                    M[e] = Mq[a * W + b]; M[DD + e] = Mq[a * W + D + b];
+                    M[2 * DD + e] = Mp[a * W + b]; M[3 * DD + e] = Mp[a * W + D + b];
+                }
+            }
+            if (diag) {
+                for (int e = tid; e < DD; e += nth) {
+                    const int a = e / D, b = e - a * D;
+                    const double sta = vec[a], ista = vec[D + a], sib = vec[2 * D + b], isib = vec[3 * D + b];
+                    mat[e] = c_make(0.5 * (sta * isib * Mq[a * W + b] + ista * sib * Mp[a * W + D + b]),
+                                    0.5 * (-SC_HBAR * sta * sib * Mq[a * W + D + b]
+                                           + (1.0 / SC_HBAR) * ista * isib * Mp[a * W + b]));
+                }
+                __syncthreads();
+            } else {
+                general_prefactor_matrix(A.hk, Mq, Mq + D, Mp, Mp + D, W, X, mat);
+            }
+        }
+
+        // ---------------- phase C: c2 = det(mat), branch tracking ----------------
+        const cplx det = lds_lu_det(mat, dp, ipiv);
+        if (tid == 0) {
+            cplx *c2 = (cplx *)A.st.c2;
+            if (do_step) {
+                const cplx prev = c2[tr];
+                if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
+            } else {
+                A.st.sgn[tr] = 1.0;
+            }
+            c2[tr] = det;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && A.epart) A.epart[blockIdx.x] = esum;
+}
+
+}  // namespace
+
+static int step_threads(int D) { return D * D <= 256 ? 64 : 256; }
+
+extern "C" int sc_step_grid(int64_t n, int32_t dim) {
+    int64_t cap = (step_threads(dim) == 64) ? 256 * 16 : 256 * 4;
+    return (int)(n < cap ? (n > 0 ? n : 1) : cap);
+}
+
+extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, double dt,
+                          int32_t mode, double *energy_partials, void *stream) {
+    if (!pot || !st || !hk) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: null argument");
+    const int D = st->dim;
+    if (pot->dim != D || hk->dim != D) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: dimension mismatch");
+    if (D < 1 || D > 64 || hk->dprime < 1 || hk->dprime > D)
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_step: D=%d d'=%d outside 1..64", D, hk->dprime);
+    if (hk->diag && hk->dprime != D) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: diag prefactor needs d' == D");
+    if (st->n <= 0) return SC_OK;
+    const bool dense = pot->kind == SC_POT_HARMONIC_DENSE;
+    if (!dense && pot->kind != SC_POT_MORSE && pot->kind != SC_POT_HARMONIC_SEP && pot->kind != SC_POT_EPS_MORSE)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown potential kind %d", pot->kind);
+    const size_t DD = (size_t)D * D, dp = hk->dprime;
+    size_t doubles = 32 + 2 + 2 * ((4 * D + 1) & ~1) + 2 * dp * dp + (hk->diag ? 0 : 2 * D * dp);
+    if (dense) doubles += 7 * 2 * DD + DD + D;
+    const size_t lds = doubles * sizeof(double) + 16;
+    if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_step: needs %zu B of LDS (D=%d)", lds, D);
+    StepArgs a{*pot, *st, *hk, dt, mode, energy_partials};
+    const int threads = step_threads(D), grid = sc_step_grid(st->n, D);
+    hipStream_t s = (hipStream_t)stream;
+    if (dense) {
+        if (hipFuncSetAttribute((const void *)hk_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return sc_check_launch("sc_hk_step (LDS attribute)");
+        hipLaunchKernelGGL(hk_step_kernel<true>, dim3(grid), dim3(threads), lds, s, a);
+    } else {
+        if (hipFuncSetAttribute((const void *)hk_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return sc_check_launch("sc_hk_step (LDS attribute)");
+        hipLaunchKernelGGL(hk_step_kernel<false>, dim3(grid), dim3(threads), lds, s, a);
+    }
+    return sc_check_launch("sc_hk_step");
+}

@@ -1,0 +1,350 @@
+"""Semiclassical propagators on MI355X.
+
+Host-side mirror of the reference's propagator interface
+(semiclassical/propagators.py: ``HermanKlukPropagator`` :407, same method
+names, argument meaning and error behaviour) over the HIP kernels of
+``libsemiclassical_hip.so``.  Python only prepares O(D^2) constants and issues
+kernel launches; all per-trajectory arithmetic runs on the GPU.
+
+Differences a caller can observe:
+  * the state lives in an engine-native, trajectory-major layout; the
+    reference's ``(rows, n)`` tensor is produced on demand by the ``y``
+    property (and accepted by its setter);
+  * ``step()`` does not synchronise: the energy-conservation guard
+    (reference propagators.py:385-398) is evaluated on the device and raised,
+    with the reference's message, at the next host synchronisation point
+    (``autocorrelation()``, ``ic_correlation()``, ``synchronize()``, ``run()``);
+  * ``run()`` executes the caller loop of cli.py:401-436 (correlate,
+    correlate, step -- nt times) without any host synchronisation.
+"""
+import logging
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, hostmath
+from ._lib import lib, check, ptr, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts
+from .units import hbar
+
+__all__ = ['HermanKlukPropagator']
+
+logger = logging.getLogger(__name__)
+
+C128 = torch.complex128
+F64 = torch.float64
+
+
+def _resolve_device(device):
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise RuntimeError(
+            f"semiclassical_amd propagators run on an AMD GPU (device='cuda[:i]'), got device='{device}'. "
+            "There is no CPU path.")
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
+class HermanKlukPropagator(object):
+    """Herman-Kluk frozen-Gaussian propagator (reference propagators.py:407-1066)."""
+
+    def __init__(self, Gamma_i, Gamma_t, device='cuda'):
+        Gamma_i, Gamma_t = hostmath.as_f64(Gamma_i), hostmath.as_f64(Gamma_t)
+        assert hostmath.is_symmetric_non_negative(Gamma_i), "Gamma_i has to be symmetric and positive semi-definite."
+        assert hostmath.is_symmetric_non_negative(Gamma_t), "Gamma_t has to be symmetric and positive semi-definite."
+        self.device = _resolve_device(device)
+        self._Gi, self._Gt = Gamma_i, Gamma_t                 # host copies (setup algebra)
+        self.Gamma_i, self.Gamma_t = Gamma_i.to(self.device), Gamma_t.to(self.device)
+        self.sqGi, self.isqGi = hostmath.sym_sqrtm(Gamma_i)
+        self.sqGt, self.isqGt = hostmath.sym_sqrtm(Gamma_t)
+        self._energy_means = None
+        self._nac = None
+        self._ntraj_norm = None
+
+    # ------------------------------------------------------------------ initial conditions
+    def initial_conditions(self, q0, p0, Gamma_0, ntraj=5000, ntraj_total=None, generator=None):
+        """Sample ``ntraj`` phase-space points from |<qi,pi,Gamma_i|q0,p0,Gamma_0>|^2 and reset the state.
+
+        The standard-normal deviates are drawn on the host with the same call the reference makes
+        (propagators.py:537-539), so on a given torch build ``torch.manual_seed(s)`` reproduces the
+        reference's CPU initial conditions.  ``ntraj_total`` (default ``ntraj``) is the N of the
+        Monte-Carlo weight 1/(N P(qi,pi)); a rank that owns one shard of a larger batch passes the
+        global count.
+        """
+        q0, p0, Gamma_0 = hostmath.as_f64(q0), hostmath.as_f64(p0), hostmath.as_f64(Gamma_0)
+        assert Gamma_0.size() == self._Gi.size(), "Width parameter matrix Gamma_0 has wrong dimensions."
+        assert hostmath.is_symmetric_non_negative(Gamma_0), "Gamma_0 has to be symmetric and positive semi-definite."
+        d = q0.size()[0]
+        U, iGi0, iLz, detLz, dprime = hostmath.sampling_matrices(self._Gi, Gamma_0)
+        if generator is None:
+            xi = torch.distributions.Normal(torch.zeros(2 * dprime, dtype=F64),
+                                            torch.ones(2 * dprime, dtype=F64)).sample((ntraj,)).T
+        else:
+            xi = torch.randn((ntraj, 2 * dprime), dtype=F64, generator=generator).T
+        z0 = torch.cat((q0, p0))
+        zi = z0.unsqueeze(1) + torch.einsum('ji,jn->in', iLz, xi)
+        probi = detLz / (2 * np.pi) ** d * torch.exp(-0.5 * torch.einsum('in,in->n', xi, xi))
+        self.set_initial_conditions(q0, p0, Gamma_0, zi, probi, ntraj_total=ntraj_total)
+
+    def set_initial_conditions(self, q0, p0, Gamma_0, zi, probi, ntraj_total=None):
+        """Start from given phase-space points ``zi`` (2D, n) with sampling densities ``probi`` (n,)."""
+        q0, p0, Gamma_0 = hostmath.as_f64(q0), hostmath.as_f64(p0), hostmath.as_f64(Gamma_0)
+        dev = self.device
+        d, n = q0.size()[0], zi.shape[1]
+        assert zi.shape[0] == 2 * d and probi.shape[0] == n
+        U, iGi0, _, _, dprime = hostmath.sampling_matrices(self._Gi, Gamma_0)
+        self.dim, self.ntraj = d, n
+        self._ntraj_norm = n if ntraj_total is None else int(ntraj_total)
+        self._q0h, self._p0h, self._G0h, self._iGi0h = q0, p0, Gamma_0, iGi0
+        self.q0, self.p0, self.Gamma_0 = q0.to(dev), p0.to(dev), Gamma_0.to(dev)
+        self.U, self.iGi0 = U.to(dev), iGi0.to(dev)
+        self.zi = torch.as_tensor(zi, dtype=F64).to(dev).contiguous()
+        self.probi = torch.as_tensor(probi, dtype=F64).to(dev).contiguous()
+
+        # ---- engine state (trajectory-major) ----
+        self._zi_t = self.zi.t().contiguous()                          # [n][2D]
+        self._qp = self._zi_t.clone()
+        self._act = torch.zeros(n, dtype=F64, device=dev)
+        self._mono = torch.zeros((n, 4, d, d), dtype=F64, device=dev)
+        eye = torch.eye(d, dtype=F64, device=dev)
+        self._mono[:, 0] = eye
+        self._mono[:, 3] = eye
+        self._c2 = torch.ones(n, dtype=C128, device=dev)
+        self._sgn = torch.ones(n, dtype=F64, device=dev)
+        self._state = sc_state(n=n, dim=d, qp=ptr(self._qp), act=ptr(self._act), mono=ptr(self._mono),
+                               c2=ptr(self._c2), sgn=ptr(self._sgn))
+        # ---- per-step scratch ----
+        self._gstep = lib.sc_step_grid(n, d)
+        self._gcorr = lib.sc_correlate_grid(n, d)
+        self._epart = torch.zeros(self._gstep, dtype=F64, device=dev)
+        self._cpart = torch.zeros((self._gcorr, 4), dtype=F64, device=dev)
+        self._cq = torch.zeros(n, dtype=C128, device=dev)
+        self._kq = torch.zeros(n, dtype=C128, device=dev)
+        self._slot = torch.zeros(8, dtype=F64, device=dev)
+        self._elog = torch.zeros(4, dtype=F64, device=dev)            # energy guard log (sc_energy_guard)
+        self._nsteps = 0
+        self._corr_step, self._corr_has_nac = -1, False
+        self._nac, self._nac_key = None, None
+
+        self._prepare()
+        self.t = 0.0
+        self._prefactor_initial()
+
+    def _prepare(self):
+        """constants of the three overlaps and of the prefactor (reference propagators.py:633-643)"""
+        dev = self.device
+        self._pre = hostmath.PrefactorConstants(self._Gi, self._Gt, self.U.cpu())
+        up = lambda x: x.contiguous().to(dev)
+        self._pre_bufs = ([up(self._pre.st), up(self._pre.si)] if self._pre.diag else
+                          [up(self._pre.L1), up(self._pre.L2), up(self._pre.R1), up(self._pre.R2)])
+        b = self._pre_bufs
+        if self._pre.diag:
+            self._hk = sc_hk_consts(dim=self.dim, dprime=self.dim, diag=1, st=ptr(b[0]), si=ptr(b[1]))
+        else:
+            self._hk = sc_hk_consts(dim=self.dim, dprime=self._pre.dprime, diag=0,
+                                    L1=ptr(b[0]), L2=ptr(b[1]), R1=ptr(b[2]), R2=ptr(b[3]))
+        self._ovl_i0, self._ovl_i0_bufs = self._overlap_consts(self._Gi, self._G0h)
+        self._ovl_t0, self._ovl_t0_bufs = self._overlap_consts(self._Gt, self._G0h)
+        # <qi,pi,Gamma_i|phi(0)> does not depend on time: evaluate once (reference recomputes it every step, :794-795)
+        self._vi = torch.zeros(self.ntraj, dtype=C128, device=dev)
+        check(lib.sc_overlap(self._ovl_i0, ptr(self._zi_t), self.ntraj, ptr(self._vi), self._stream()))
+
+    def _overlap_consts(self, Gbra, Gket):
+        oc = hostmath.OverlapConstants(Gbra, Gket)
+        dev = self.device
+        if oc.diag:
+            mats = [torch.diagonal(m).contiguous().to(dev) for m in (oc.A, oc.B, oc.C)]
+        else:
+            mats = [m.contiguous().to(dev) for m in (oc.A, oc.B, oc.C)]
+        bufs = mats + [self.q0, self.p0]
+        c = sc_overlap_consts(dim=self.dim, diag=int(oc.diag), A=ptr(bufs[0]), B=ptr(bufs[1]), C=ptr(bufs[2]),
+                              qk=ptr(self.q0), pk=ptr(self.p0), fac=oc.fac)
+        return c, bufs
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _prefactor_initial(self):
+        """prefactor at t = 0 and initialisation of the branch tracker (reference propagators.py:631)"""
+        check(lib.sc_hk_step(_NULL_POT(self.dim), self._state, self._hk, 0.0, 1, None, self._stream()))
+
+    # ------------------------------------------------------------------ time stepping
+    def step(self, potential, dt):
+        """propagate all trajectories by one RK4 step t -> t+dt (reference propagators.py:645-655)"""
+        assert self.dim == potential.dimensions(), "potential has wrong dimensions"
+        self._launch_step(potential, float(dt))
+        self.t += float(dt)
+
+    def _launch_step(self, potential, dt):
+        desc = self._potential_descriptor(potential)
+        s = self._stream()
+        check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
+        check(lib.sc_energy_guard(ptr(self._epart), self._gstep, float(self.ntraj), ptr(self._elog), s))
+        self._nsteps += 1
+        self._remember_nac(potential)
+
+    def _potential_descriptor(self, potential):
+        if not hasattr(potential, "_descriptor"):
+            raise NotImplementedError(
+                f"{type(potential).__name__} has no device descriptor; use the potentials of "
+                "semiclassical_amd.potentials (generic Python potentials are not supported by the HIP engine yet).")
+        with torch.cuda.device(self.device):
+            return potential._descriptor(self.device)
+
+    def _check_energy_guard(self):
+        """raise the reference's RuntimeError (propagators.py:396) if <T+V> jumped by more than 1e-2 Hartree"""
+        change = float(self._elog[2].item())
+        if change > 1.0e-2:
+            raise RuntimeError(f"average energy of classical trajectories is not conserved, change= {change} Hartree")
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check_energy_guard()
+
+    # ------------------------------------------------------------------ correlation functions
+    def _remember_nac(self, potential):
+        key = id(potential)
+        if self._nac_key == key:
+            return
+        masses = hostmath.as_f64(potential.masses())
+        probe = torch.zeros((self.dim, 1), dtype=F64)
+        tau1 = hostmath.as_f64(potential.derivative_coupling_1st(probe))[:, 0]
+        tau2 = hostmath.as_f64(potential.derivative_coupling_2nd(probe))[:, 0]
+        nc = hostmath.NacConstants(self._G0h, self._Gi, self._iGi0h, self._p0h, masses, tau1,
+                                   tau2_sum=float(torch.sum(tau2 / masses)))
+        dev = self.device
+        bufs = [nc.rn.to(dev), nc.gn.to(dev)]
+        self._nac = sc_nac_consts(dim=self.dim, rn=ptr(bufs[0]), gn=ptr(bufs[1]), q0=ptr(self.q0), p0=ptr(self.p0),
+                                  p0n1=nc.p0n1, n2=nc.n2)
+        self._nac_bufs, self._nac_key = bufs, key
+        self._nacq = torch.zeros(self.ntraj, dtype=C128, device=dev)
+        check(lib.sc_nac_initial(self._nac, ptr(self._zi_t), self.ntraj, ptr(self._nacq), self._stream()))
+
+    def _mc_norm(self):
+        return self._ntraj_norm * (2 * np.pi * hbar) ** self.dim
+
+    def _launch_correlate(self, slot_ptr, per_trajectory=True):
+        """per-trajectory terms + their sums for the current state into the 5-double slot at `slot_ptr`"""
+        s = self._stream()
+        nac = self._nac
+        check(lib.sc_hk_correlate(self._state, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
+                                  ptr(self._nacq) if nac is not None else None, self._mc_norm(),
+                                  ptr(self._cq) if per_trajectory else None,
+                                  ptr(self._kq) if per_trajectory else None, ptr(self._cpart), s))
+        check(lib.sc_reduce_slot(ptr(self._cpart), self._gcorr, None, 0, 1.0, C_void(slot_ptr), s))
+
+    def _correlate_current(self, need_nac):
+        if self._corr_step == self._nsteps and (self._corr_has_nac or not need_nac):
+            return
+        self._launch_correlate(self._slot.data_ptr())
+        self._corr_step, self._corr_has_nac = self._nsteps, self._nac is not None
+        self._slot_host = self._slot.cpu().numpy().copy()          # host sync
+        self._check_energy_guard()
+
+    def autocorrelation_qp(self):
+        """per-trajectory terms of the autocorrelation function (reference propagators.py:784-807)"""
+        self._correlate_current(False)
+        return self._cq * (self._mc_norm() * self.probi)
+
+    def autocorrelation(self, energy0_es=0.0):
+        """C_auto(t) = e^{i t E0/hbar} <phi(0)|phi(t)> for the current step (reference propagators.py:809-843)"""
+        self._correlate_current(False)
+        c = complex(self._slot_host[0], self._slot_host[1])
+        return c * np.exp(1j / hbar * self.t * energy0_es)
+
+    def ic_correlation(self, potential, energy0_es=0.0):
+        """k_ic(t) for the current step (reference propagators.py:845-911)"""
+        self._remember_nac(potential)
+        self._correlate_current(True)
+        k = complex(self._slot_host[2], self._slot_host[3])
+        return k * np.exp(1j / hbar * self.t * energy0_es)
+
+    def run(self, potential, dt, nt, energy0_es=0.0, slots=None):
+        """The caller loop of cli.py:401-436 on the device: ``nt`` times (C_auto, k_ic, step), no host sync.
+
+        Returns ``(autocorrelation[nt], ic_correlation[nt])`` as complex NumPy arrays.  With ``slots`` (a
+        device tensor (nt, 5)) the raw sums are left on the device for a later flush (see distributed.py)
+        and ``None`` is returned.
+        """
+        assert self.dim == potential.dimensions(), "potential has wrong dimensions"
+        dt = float(dt)
+        self._remember_nac(potential)
+        own = slots is None
+        if own:
+            slots = torch.zeros((nt, 5), dtype=F64, device=self.device)
+        t0 = self.t
+        base = slots.data_ptr()
+        for k in range(nt):
+            self._launch_correlate(base + 40 * k, per_trajectory=False)
+            self._launch_step(potential, dt)
+            self.t += dt
+        self._corr_step = -1
+        if not own:
+            return None
+        self.synchronize()
+        return self.finalize_slots(slots, t0, dt, energy0_es)
+
+    @staticmethod
+    def finalize_slots(slots, t0, dt, energy0_es):
+        """apply the dynamical phase e^{i t E0/hbar} (reference propagators.py:841, 906) on the host"""
+        raw = slots.detach().cpu().numpy()
+        times = t0 + hostmath.time_grid(raw.shape[0], dt)
+        phase = np.exp(1j / hbar * times * energy0_es)
+        return (raw[:, 0] + 1j * raw[:, 1]) * phase, (raw[:, 2] + 1j * raw[:, 3]) * phase
+
+    # ------------------------------------------------------------------ data access (reference :914-948)
+    @property
+    def y(self):
+        """state in the reference's layout: rows (q, p, Mqq, Mqp, Mpq, Mpp, S), trajectories fastest"""
+        d, n = self.dim, self.ntraj
+        out = torch.empty((2 * d + 4 * d * d + 1, n), dtype=F64, device=self.device)
+        check(lib.sc_state_to_reference(self._state, ptr(out), self._stream()))
+        return out
+
+    @y.setter
+    def y(self, value):
+        value = torch.as_tensor(value, dtype=F64).to(self.device).contiguous()
+        d, n = self.dim, self.ntraj
+        assert value.shape == (2 * d + 4 * d * d + 1, n)
+        check(lib.sc_state_from_reference(ptr(value), self._state, self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()     # `value` may be a temporary
+        self._corr_step = -1
+
+    @property
+    def c(self):
+        """unsigned prefactor sqrt(c2) (principal branch), as the reference's attribute"""
+        return torch.sqrt(self._c2)
+
+    def initial_positions_and_momenta(self):
+        return torch.split(self.zi, [self.dim, self.dim])
+
+    def current_positions_and_momenta(self):
+        qp = self._qp.t()
+        return qp[:self.dim], qp[self.dim:]
+
+    def classical_action(self):
+        return self._act
+
+    def monodromy_matrices(self):
+        # (n, D, D) -> (D, D, n) views
+        return tuple(self._mono[:, k].permute(1, 2, 0) for k in range(4))
+
+    def semiclassical_prefactor(self):
+        return self._sgn * torch.sqrt(self._c2)
+
+    def _get_signs_of_sqrt(self, key):
+        if key != "prefactorC":
+            logger.error(f"Apparently the sign of the square root of the quantity '{key}' is not being tracked.")
+            raise KeyError(key)
+        return self._sgn.type(C128)
+
+
+def C_void(address):
+    import ctypes
+    return ctypes.c_void_p(int(address))
+
+
+def _NULL_POT(dim):
+    """descriptor for prefactor-only launches (the potential is not touched in mode 1)"""
+    return _lib.sc_potential(kind=_lib.SC_POT_HARMONIC_SEP, dim=dim)
