@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Headline benchmark: trajectory-steps/s of the HK loop on the synthetic 60-mode anharmonic-AS model.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ntraj n_per_gpu]
+
+A "step" is one pass of the hot path over one batch: (C_auto, k_ic, RK4 step + prefactor) for all
+trajectories (the loop body of reference cli.py:401-436).  Workload = BASELINE.json configs[1]:
+anharmonic-AS, D = 60, 10^5 trajectories per GPU, HK, fp64, dt = 0.005 fs.
+Inputs are resident in HBM before the timed region; the timed region ends with the single all-reduce
+of the accumulated correlation sums (the "flush").  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def as60_model():
+    """synthetic 60-mode AS model, SURVEY.md section 8d config 2"""
+    from semiclassical_amd import units
+    rng = np.random.default_rng(60)
+    omega_cm = np.linspace(160.0, 3300.0, 60)
+    S = rng.uniform(0, 0.1, 60) * rng.choice([-1, 1], 60)
+    nac = rng.normal(0, 1e-4, 60)
+    chi = np.full(60, 0.02)
+    omega = torch.from_numpy(omega_cm / units.hartree_to_wavenumbers)
+    S, nac, chi = torch.from_numpy(S), torch.from_numpy(nac), torch.from_numpy(chi)
+    q0 = torch.sqrt(2.0 * abs(S) / omega) * torch.sign(S)
+    dt = 0.005 / units.autime_to_fs
+    return omega, chi, nac, q0, dt
+
+
+def algorithmic_bytes_per_traj_step(D):
+    """read y + write y + per-trajectory side data = 64 D^2 + 64 D + 72"""
+    return 64 * D * D + 64 * D + 72
+
+
+def cpu_baseline(omega, chi, nac, q0, dt, n=1000, nt=4):
+    """the CPU oracle (torch eager restatement of the reference's op sequence) on a bounded sample"""
+    from oracle import sc_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    G = torch.diag(omega)
+    E0 = float(0.5 * omega.sum())
+    pot = orc.MorseOracle(omega, chi.clone(), nac)
+    prop = orc.HKOracle(G, G)
+    torch.manual_seed(0)
+    prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n)
+    orc.run_loop(prop, pot, dt, 1, E0)                      # warm-up step
+    t0 = time.perf_counter()
+    orc.run_loop(prop, pot, dt, nt, E0)
+    wall = time.perf_counter() - t0
+    return {"value": n * nt / wall, "unit": "trajectory-steps/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"D=60 anharmonic-AS, n={n}, {nt} steps after 1 warm-up step, {wall:.1f} s wall, "
+                                      f"torch {torch.__version__} CPU eager"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ntraj", type=int, default=100000, help="trajectories per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    torch.set_default_dtype(torch.float64)
+    from semiclassical_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    from semiclassical_amd import potentials as P, propagators as PR
+
+    omega, chi, nac, q0, dt = as60_model()
+    dim = omega.shape[0]
+    G = torch.diag(omega)
+    E0 = float(0.5 * omega.sum())
+    n = args.ntraj
+    pot = P.MorsePotential(omega, chi.clone(), nac)
+    prop = PR.HermanKlukPropagator(G, G, device=dev)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, ntraj_total=n * world, generator=gen)
+
+    K, W = args.steps, args.warmup
+    slots = torch.zeros((K, 5), dtype=torch.float64, device=dev)
+    wslots = torch.zeros((max(W, 1), 5), dtype=torch.float64, device=dev)
+    if W > 0:
+        prop.run(pot, dt, W, E0, slots=wslots)
+        D.flush_correlations(wslots)
+    prop.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- timed region: exactly K steps + the flush ----
+    prop.profile_step_kernel = True     # HIP events around the step-kernel launches (same stream)
+    barrier()
+    t0 = time.perf_counter()
+    prop.run(pot, dt, K, E0, slots=slots)
+    D.flush_correlations(slots)
+    barrier()
+    wall = time.perf_counter() - t0
+    prop.profile_step_kernel = False
+    prop.synchronize()
+
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+    cauto, kic = prop.finalize_slots(slots, prop.t - K * dt, dt, E0)
+    assert np.isfinite(cauto).all() and np.isfinite(kic).all(), "NaN in correlation functions"
+
+    if rank == 0:
+        step_ms = prop.step_kernel_times_ms()
+        kern_ms = float(np.mean(step_ms))
+        abytes = algorithmic_bytes_per_traj_step(dim) * n
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "trajectory-steps/sec + wall-time to converged C(t), anharmonic-AS D=60",
+            "value": n * world * K / wall, "unit": "trajectory-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "anharmonic-AS 60-mode, HK, fp64, dt=0.005 fs (BASELINE.json configs[1])",
+                       "trajectories_per_gpu": n, "trajectories_total": n * world, "dim": dim,
+                       "sharding": f"{world} x {n} trajectories, one all-reduce of 4*K doubles per flush"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "hk_step_kernel<false>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": abytes},
+            "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(omega, chi, nac, q0, dt)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

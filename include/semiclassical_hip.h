@@ -65,6 +65,8 @@ typedef struct sc_state {
     double *mono;
     double *c2;
     double *sgn;
+    int32_t *flags;         /* [n], zero-initialised scratch: trajectories whose determinant the fast
+                               path hands to the fully pivoted elimination (may be NULL) */
 } sc_state;
 
 /* constants of the HK prefactor, reference propagators.py:951-1004.

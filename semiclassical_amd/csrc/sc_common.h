@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "semiclassical_hip.h"
 
@@ -80,6 +81,52 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
         for (int w = 0; w < nw; ++w) s += red[w * NV + i];
         v[i] = s;
     }
+}
+
+// ---- shared by the step kernels ----
+struct StepArgs {
+    sc_potential pot;
+    sc_state st;
+    sc_hk_consts hk;
+    double dt;
+    int mode;
+    double *epart;
+};
+
+// V, dV/dx, d2V/dx2 of one mode of a separable potential
+__device__ __forceinline__ void sep_eval(int kind, double c0, double c1, double x, double &v, double &g, double &h) {
+    if (kind == SC_POT_MORSE) {                    // c0 = a, c1 = De
+        double e = exp(-c0 * x);
+        double om = 1.0 - e;
+        v = c1 * om * om;
+        g = 2.0 * c0 * c1 * e * om;
+        h = 2.0 * c0 * c0 * c1 * e * (2.0 * e - 1.0);
+    } else if (kind == SC_POT_HARMONIC_SEP) {      // c0 = omega^2
+        v = 0.5 * c0 * x * x;
+        g = c0 * x;
+        h = c0;
+    } else {                                       // SC_POT_EPS_MORSE: c0 = eps, c1 = b
+        double e1 = exp(-c1 * x), e2 = exp(-2.0 * c1 * x);
+        double om = 1.0 - e1;
+        v = c0 / (2.0 * c1 * c1) * om * om + (1.0 - c0) * 0.5 * x * x;
+        g = c0 / c1 * (e1 - e2) + (1.0 - c0) * x;
+        h = c0 * (2.0 * e2 - e1) + (1.0 - c0);
+    }
+}
+
+// RK4 of the pair (u, v) with du/dt = v/m, dv/dt = -h(t) u  (diagonal Hessian)
+__device__ __forceinline__ void rk4_pair(double &u, double &v, double im, double h1, double h2, double h3, double h4,
+                                         double dt) {
+    const double hh = 0.5 * dt, h6 = dt / 6.0;
+    double k1u = v * im, k1v = -h1 * u;
+    double u2 = u + hh * k1u, v2 = v + hh * k1v;
+    double k2u = v2 * im, k2v = -h2 * u2;
+    double u3 = u + hh * k2u, v3 = v + hh * k2v;
+    double k3u = v3 * im, k3v = -h3 * u3;
+    double u4 = u + dt * k3u, v4 = v + dt * k3v;
+    double k4u = v4 * im, k4v = -h4 * u4;
+    u = u + h6 * (k1u + 2.0 * k2u + 2.0 * k3u + k4u);
+    v = v + h6 * (k1v + 2.0 * k2v + 2.0 * k3v + k4v);
 }
 
 // host-side error plumbing (sc_api.hip)

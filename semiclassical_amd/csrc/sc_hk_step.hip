@@ -15,51 +15,6 @@
 
 namespace {
 
-struct StepArgs {
-    sc_potential pot;
-    sc_state st;
-    sc_hk_consts hk;
-    double dt;
-    int mode;
-    double *epart;
-};
-
-// V, dV/dx, d2V/dx2 of one mode of a separable potential
-__device__ __forceinline__ void sep_eval(int kind, double c0, double c1, double x, double &v, double &g, double &h) {
-    if (kind == SC_POT_MORSE) {                    // c0 = a, c1 = De
-        double e = exp(-c0 * x);
-        double om = 1.0 - e;
-        v = c1 * om * om;
-        g = 2.0 * c0 * c1 * e * om;
-        h = 2.0 * c0 * c0 * c1 * e * (2.0 * e - 1.0);
-    } else if (kind == SC_POT_HARMONIC_SEP) {      // c0 = omega^2
-        v = 0.5 * c0 * x * x;
-        g = c0 * x;
-        h = c0;
-    } else {                                       // SC_POT_EPS_MORSE: c0 = eps, c1 = b
-        double e1 = exp(-c1 * x), e2 = exp(-2.0 * c1 * x);
-        double om = 1.0 - e1;
-        v = c0 / (2.0 * c1 * c1) * om * om + (1.0 - c0) * 0.5 * x * x;
-        g = c0 / c1 * (e1 - e2) + (1.0 - c0) * x;
-        h = c0 * (2.0 * e2 - e1) + (1.0 - c0);
-    }
-}
-
-// RK4 of the pair (u, v) with du/dt = v/m, dv/dt = -h(t) u  (diagonal Hessian)
-__device__ __forceinline__ void rk4_pair(double &u, double &v, double im, double h1, double h2, double h3, double h4,
-                                         double dt) {
-    const double hh = 0.5 * dt, h6 = dt / 6.0;
-    double k1u = v * im, k1v = -h1 * u;
-    double u2 = u + hh * k1u, v2 = v + hh * k1v;
-    double k2u = v2 * im, k2v = -h2 * u2;
-    double u3 = u + hh * k2u, v3 = v + hh * k2v;
-    double k3u = v3 * im, k3v = -h3 * u3;
-    double u4 = u + dt * k3u, v4 = v + dt * k3v;
-    double k4u = v4 * im, k4v = -h4 * u4;
-    u = u + h6 * (k1u + 2.0 * k2u + 2.0 * k3u + k4u);
-    v = v + h6 * (k1v + 2.0 * k2v + 2.0 * k3v + k4v);
-}
-
 // det of the d x d complex matrix A (LDS, row-major), LU with partial pivoting; A is destroyed.
 // Every thread returns the determinant.  `ipiv` is one LDS int.
 __device__ cplx lds_lu_det(cplx *A, int d, int *ipiv) {
@@ -151,7 +106,11 @@ __global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x, nth = blockDim.x;
     const int dp = A.hk.dprime;
     const bool diag = A.hk.diag != 0;
-    const bool do_step = A.mode == 0;
+    // mode & 0xff: 0 = step + prefactor, 1 = prefactor only + tracker initialisation
+    // mode & 0x200: fix-up pass -- only trajectories flagged by the fast path, prefactor + tracking only
+    const bool fixup = (A.mode & 0x200) != 0;
+    const bool do_step = (A.mode & 0xff) == 0 && !fixup;
+    const bool init_track = (A.mode & 0xff) == 1;
     const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
 
     // ---- LDS carve-up (all offsets even => 16-byte aligned) ----
@@ -181,6 +140,7 @@ __global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
 
     double esum = 0.0;
     for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        if (fixup && A.st.flags[tr] == 0) continue;          // uniform over the workgroup
         double *qp = A.st.qp + tr * 2 * D;
         double *M = A.st.mono + tr * 4 * (int64_t)DD;
         double im = 1.0;
@@ -331,20 +291,23 @@ __global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
         const cplx det = lds_lu_det(mat, dp, ipiv);
         if (tid == 0) {
             cplx *c2 = (cplx *)A.st.c2;
-            if (do_step) {
+            if (!init_track) {
                 const cplx prev = c2[tr];
                 if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
             } else {
                 A.st.sgn[tr] = 1.0;
             }
             c2[tr] = det;
+            if (fixup) A.st.flags[tr] = 0;
         }
         __syncthreads();
     }
-    if (tid == 0 && A.epart) A.epart[blockIdx.x] = esum;
+    if (tid == 0 && A.epart && !fixup) A.epart[blockIdx.x] = esum;
 }
 
 }  // namespace
+
+int sc_launch_step_sd(const StepArgs &a, hipStream_t s);   // sc_hk_step_sd.hip
 
 static int step_threads(int D) { return D * D <= 256 ? 64 : 256; }
 
@@ -365,6 +328,14 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     const bool dense = pot->kind == SC_POT_HARMONIC_DENSE;
     if (!dense && pot->kind != SC_POT_MORSE && pot->kind != SC_POT_HARMONIC_SEP && pot->kind != SC_POT_EPS_MORSE)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown potential kind %d", pot->kind);
+    const bool fast = !dense && hk->diag && !getenv("SC_FORCE_GENERAL_STEP");
+    if (fast) {
+        const int dbg = (getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0) | (getenv("SC_DEBUG_FORCE_FIXUP") ? 0x400 : 0);
+        StepArgs a{*pot, *st, *hk, dt, mode | dbg, energy_partials};
+        const int rc = sc_launch_step_sd(a, (hipStream_t)stream);
+        if (rc != SC_OK || !st->flags || (dbg & 0x100)) return rc;
+        mode |= 0x200;      // fully pivoted fix-up of the trajectories the fast path flagged (normally none)
+    }
     const size_t DD = (size_t)D * D, dp = hk->dprime;
     size_t doubles = 32 + 2 + 2 * ((4 * D + 1) & ~1) + 2 * dp * dp + (hk->diag ? 0 : 2 * D * dp);
     if (dense) doubles += 7 * 2 * DD + DD + D;

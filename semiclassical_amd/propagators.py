@@ -112,8 +112,9 @@ class HermanKlukPropagator(object):
         self._mono[:, 3] = eye
         self._c2 = torch.ones(n, dtype=C128, device=dev)
         self._sgn = torch.ones(n, dtype=F64, device=dev)
+        self._flags = torch.zeros(n, dtype=torch.int32, device=dev)
         self._state = sc_state(n=n, dim=d, qp=ptr(self._qp), act=ptr(self._act), mono=ptr(self._mono),
-                               c2=ptr(self._c2), sgn=ptr(self._sgn))
+                               c2=ptr(self._c2), sgn=ptr(self._sgn), flags=ptr(self._flags))
         # ---- per-step scratch ----
         self._gstep = lib.sc_step_grid(n, d)
         self._gcorr = lib.sc_correlate_grid(n, d)
@@ -179,7 +180,15 @@ class HermanKlukPropagator(object):
     def _launch_step(self, potential, dt):
         desc = self._potential_descriptor(potential)
         s = self._stream()
-        check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
+        if getattr(self, "profile_step_kernel", False):
+            # HIP events on the launch stream, bracketing only the step kernel (bench.py roofline)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
+            e1.record()
+            self.__dict__.setdefault("_step_events", []).append((e0, e1))
+        else:
+            check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
         check(lib.sc_energy_guard(ptr(self._epart), self._gstep, float(self.ntraj), ptr(self._elog), s))
         self._nsteps += 1
         self._remember_nac(potential)
@@ -201,6 +210,11 @@ class HermanKlukPropagator(object):
     def synchronize(self):
         torch.cuda.current_stream(self.device).synchronize()
         self._check_energy_guard()
+
+    def step_kernel_times_ms(self):
+        """durations of the step-kernel launches recorded while ``profile_step_kernel`` was set"""
+        torch.cuda.current_stream(self.device).synchronize()
+        return [e0.elapsed_time(e1) for e0, e1 in self.__dict__.get("_step_events", [])]
 
     # ------------------------------------------------------------------ correlation functions
     def _remember_nac(self, potential):

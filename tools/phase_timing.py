@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Ablation timing of the step kernel on the bench workload (debug tool, GPU box only).
+
+Usage: python tools/phase_timing.py [ntraj]
+Times (HIP events on the launch stream): the full step, the step without the elimination
+(SC_DEBUG_SKIP_LU=1) and the prefactor-only launch (loads + matrix + elimination, no RK4 / stores).
+"""
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from semiclassical_amd import potentials as P, propagators as PR  # noqa: E402
+from semiclassical_amd._lib import lib, check, ptr  # noqa: E402
+
+torch.set_default_dtype(torch.float64)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+omega, chi, nac, q0, dt = bench.as60_model()
+G = torch.diag(omega)
+pot = P.MorsePotential(omega, chi.clone(), nac)
+prop = PR.HermanKlukPropagator(G, G, device="cuda")
+prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(1))
+
+
+def timed(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+desc = prop._potential_descriptor(pot)
+full = lambda: check(lib.sc_hk_step(desc, prop._state, prop._hk, dt, 0, ptr(prop._epart), prop._stream()))
+pref = lambda: check(lib.sc_hk_step(desc, prop._state, prop._hk, dt, 1, None, prop._stream()))
+ab = bench.algorithmic_bytes_per_traj_step(60) * n
+for occ in os.environ.get("OCC_LIST", "2").split(","):
+    os.environ["SC_SD_OCC"] = occ
+    t_full = timed(full)
+    t_pref = timed(pref)
+    os.environ["SC_DEBUG_SKIP_LU"] = "1"
+    t_nolu = timed(full)
+    t_load = timed(pref)
+    del os.environ["SC_DEBUG_SKIP_LU"]
+    print(f"n={n} occ={occ}: full step {t_full:.3f} ms ({ab / t_full / 1e6:.0f} GB/s algorithmic) | without elimination "
+          f"{t_nolu:.3f} ms | prefactor only (load+mat+LU) {t_pref:.3f} ms | load+mat only {t_load:.3f} ms", flush=True)
