@@ -47,7 +47,8 @@ def algorithmic_bytes_per_traj_step(D):
 def cpu_baseline(omega, chi, nac, q0, dt, n=1000, nt=4):
     """the CPU oracle (torch eager restatement of the reference's op sequence) on a bounded sample"""
     from oracle import sc_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's share of the host: 16 cores (oversubscribing the visible CPUs stalls torch)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0)), os.cpu_count() or 1))
     G = torch.diag(omega)
     E0 = float(0.5 * omega.sum())
     pot = orc.MorseOracle(omega, chi.clone(), nac)
@@ -138,7 +139,7 @@ def main():
                        "sharding": f"{world} x {n} trajectories, one all-reduce of 4*K doubles per flush"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "hk_step_kernel<false>", "kernel_ms": kern_ms,
+                         "kernel": "hk_step_sd_kernel<4,4>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes},
             "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
         }

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsemiclassical_hip.so")
+LIB_PATH = os.environ.get("SC_LIB_PATH") or os.path.join(HERE, "libsemiclassical_hip.so")
 
 c_double_p = C.c_void_p      # device pointers travel as plain integers
 

@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libsemiclassical_hip.so")
+STAMPS_LIB = os.path.join(HERE, "libsemiclassical_hip_stamps.so")   # diagnostic build, tools/lu_stamps.py
 
 
 def sources():
@@ -26,18 +27,21 @@ def needs_build():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def build(force=False, verbose=True, extra=()):
-    if not force and not needs_build():
+def build(force=False, verbose=True, extra=(), out=None):
+    if out is None and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"),
-           "-o", LIB] + list(extra) + sources()
+           "-o", out or LIB] + list(extra) + sources()
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--stamps" in sys.argv:
+        build(force=True, extra=["-DSC_STAMPS"], out=STAMPS_LIB)
+    else:
+        build(force="--force" in sys.argv)

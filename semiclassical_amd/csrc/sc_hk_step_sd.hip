@@ -14,7 +14,7 @@
 //                                                               (propagators.py:86-119, 313-383; potentials.py)
 //   phase B  every (a,b): (Mqq,Mpq)' = P_a (Mqq,Mpq), (Mqp,Mpp)' = P_a (Mqp,Mpp), store back, and form
 //            mat_ab = 1/2[ st_a/si_b Mqq + si_b/st_a Mpp - i hbar st_a si_b Mqp + i/hbar Mpq/(st_a si_b) ]
-//            in registers; the loads of row slot ra+1 are in flight while slot ra is processed.
+//            in registers
 //                                                                            (propagators.py:969-986)
 //   phase C  c2 = det(mat) by Gaussian elimination with the matrix held in REGISTERS (NR*NR complex per
 //            thread).  Rows are eliminated in natural order; the pivot COLUMN of row k is chosen by magnitude
@@ -29,6 +29,31 @@
 //            path is exercised by tests/test_hk_gpu.py::test_weak_pivot_fallback).
 //            Then the sqrt branch tracker.                   (torch.det, propagators.py:999, 1006-1052)
 #include "sc_common.h"
+
+#ifdef SC_STAMPS
+// diagnostic build only (tools/lu_stamps.py): per-wave cycle sums of the segments of an elimination step
+__device__ unsigned long long g_stamps[4][16];
+struct Stamps {
+    unsigned long long acc[16];
+    unsigned long long last;
+    int base;
+};
+#define STAMP(st, i)                                                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        (st).acc[(st).base + (i)] += t_ - (st).last;                                          \
+        (st).last = t_;                                                                       \
+    } while (0)
+extern "C" int sc_debug_read_stamps(unsigned long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+}
+#else
+struct Stamps {};
+#define STAMP(st, i) do { } while (0)
+#endif
 
 namespace {
 
@@ -71,47 +96,15 @@ struct PivotRecord {        // published by the owner of row k together with the
     int col, pad;           // pivot column
 };
 
-// v of lane PL of the caller's 16-lane DPP row, for every lane of the row (row_newbcast, no LDS round trip)
-template <int PL>
-__device__ __forceinline__ cplx row16_bcast_dpp(cplx v) {
-    int a = __double2loint(v.x), b = __double2hiint(v.x), c = __double2loint(v.y), d = __double2hiint(v.y);
-    a = __builtin_amdgcn_update_dpp(a, a, 0x150 + PL, 0xF, 0xF, false);
-    b = __builtin_amdgcn_update_dpp(b, b, 0x150 + PL, 0xF, 0xF, false);
-    c = __builtin_amdgcn_update_dpp(c, c, 0x150 + PL, 0xF, 0xF, false);
-    d = __builtin_amdgcn_update_dpp(d, d, 0x150 + PL, 0xF, 0xF, false);
-    return c_make(__hiloint2double(b, a), __hiloint2double(d, c));
-}
-
-template <int NR, int KB, int PL>
-__device__ __forceinline__ void fetch_pivot_column(const cplx (&m)[NR][NR], cplx (&c)[NR]) {
-#pragma unroll
-    for (int ra = KB; ra < NR; ++ra) c[ra] = row16_bcast_dpp<PL>(m[ra][KB]);
-}
-
 // rank-1 update of the rows below row k = 16*KB + kt with the scaled pivot row r; pivot column = (slot KB, lane pl).
-// The pivot-column entry of a row lives in lane pl of the thread's own 16-lane group: a wave-uniform switch over
-// pl selects the matching DPP broadcast.
+// (A wave-uniform switch over pl with DPP row_newbcast instead of ds_bpermute was measured SLOWER: the 16 code
+// paths miss the instruction cache, ~900 cycles per step in tools/lu_stamps.py.)
 template <int NR, int KB>
-__device__ __forceinline__ void eliminate(cplx (&m)[NR][NR], const cplx (&r)[NR], int kt, int ti, int pl) {
+__device__ __forceinline__ void eliminate(cplx (&m)[NR][NR], const cplx (&r)[NR], int kt, int ti, int pl, Stamps &st) {
     cplx c[NR];
-    switch (pl) {
-        case 0: fetch_pivot_column<NR, KB, 0>(m, c); break;
-        case 1: fetch_pivot_column<NR, KB, 1>(m, c); break;
-        case 2: fetch_pivot_column<NR, KB, 2>(m, c); break;
-        case 3: fetch_pivot_column<NR, KB, 3>(m, c); break;
-        case 4: fetch_pivot_column<NR, KB, 4>(m, c); break;
-        case 5: fetch_pivot_column<NR, KB, 5>(m, c); break;
-        case 6: fetch_pivot_column<NR, KB, 6>(m, c); break;
-        case 7: fetch_pivot_column<NR, KB, 7>(m, c); break;
-        case 8: fetch_pivot_column<NR, KB, 8>(m, c); break;
-        case 9: fetch_pivot_column<NR, KB, 9>(m, c); break;
-        case 10: fetch_pivot_column<NR, KB, 10>(m, c); break;
-        case 11: fetch_pivot_column<NR, KB, 11>(m, c); break;
-        case 12: fetch_pivot_column<NR, KB, 12>(m, c); break;
-        case 13: fetch_pivot_column<NR, KB, 13>(m, c); break;
-        case 14: fetch_pivot_column<NR, KB, 14>(m, c); break;
-        default: fetch_pivot_column<NR, KB, 15>(m, c); break;
-    }
+#pragma unroll
+    for (int ra = KB; ra < NR; ++ra) c[ra] = row16_bcast(m[ra][KB], pl);
+    STAMP(st, 3);
     if (ti <= kt) c[KB] = c_make(0.0, 0.0);
 #pragma unroll
     for (int ra = KB; ra < NR; ++ra) {
@@ -123,12 +116,17 @@ __device__ __forceinline__ void eliminate(cplx (&m)[NR][NR], const cplx (&r)[NR]
 // all elimination steps of the diagonal block KB; returns false when a zero pivot was met
 template <int NR, int KB>
 __device__ __forceinline__ bool eliminate_block(cplx (&m)[NR][NR], cplx &det, unsigned long long &done, int D,
-                                                cplx (*rowbuf)[64], PivotRecord *pivrec, int *permseq, int *weak) {
+                                                cplx (*rowbuf)[64], PivotRecord *pivrec, int *permseq, int *weak,
+                                                Stamps &st) {
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15, lane = tid & 63;
     for (int kt = 0; kt < 16; ++kt) {
         const int k = 16 * KB + kt;
         if (k >= D) break;
         const int par = k & 1;
+#ifdef SC_STAMPS
+        st.base = ((tid >> 6) == (kt >> 2)) ? 0 : 8;      // owner wave of this step or not
+        STAMP(st, 7);                                    // (restart the clock)
+#endif
         if (ti == kt) {
             // key = upper 26 bits of |a_kj|^2 (as an integer) | (63 - j); in-block candidates and the rest of the row
             int key_blk = -1, key_out = -1;
@@ -165,37 +163,21 @@ __device__ __forceinline__ bool eliminate_block(cplx (&m)[NR][NR], cplx &det, un
                 if (any_small) *weak = 1;
             }
         }
+        STAMP(st, 0);
         __syncthreads();
+        STAMP(st, 1);
         const PivotRecord rec = pivrec[par];
         cplx r[NR];
 #pragma unroll
         for (int rb = KB; rb < NR; ++rb) r[rb] = rowbuf[par][16 * rb + tj];
+        STAMP(st, 2);
         if (rec.re == 0.0 && rec.im == 0.0) return false;
         if (tid < 64) det = c_mul(det, c_make(rec.re, rec.im));
         done |= 1ull << rec.col;
-        eliminate<NR, KB>(m, r, kt, ti, rec.col & 15);
+        eliminate<NR, KB>(m, r, kt, ti, rec.col & 15, st);
+        STAMP(st, 4);
     }
     return true;
-}
-
-template <int NR>
-struct RowSlot {            // the four monodromy planes of one row slot, NR column slots each
-    double qq[NR], qp[NR], pq[NR], pp[NR];
-};
-
-template <int NR>
-__device__ __forceinline__ void load_row_slot(RowSlot<NR> &v, const double *M, int ra, int ti, int tj, int D, int DD) {
-    const int a = 16 * ra + ti;
-#pragma unroll
-    for (int rb = 0; rb < NR; ++rb) {
-        const int b = 16 * rb + tj;
-        const bool ok = a < D && b < D;
-        const int e = a * D + b;
-        v.qq[rb] = ok ? M[e] : 0.0;
-        v.qp[rb] = ok ? M[DD + e] : 0.0;
-        v.pq[rb] = ok ? M[2 * DD + e] : 0.0;
-        v.pp[rb] = ok ? M[3 * DD + e] : 0.0;
-    }
 }
 
 template <int NR, int MINW>
@@ -228,10 +210,6 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         double *qp = A.st.qp + tr * 2 * D;
         double *M = A.st.mono + tr * 4 * (int64_t)DD;
         if (tid == 0) weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: debug, force the fallback (SC_DEBUG_FORCE_FIXUP)
-
-        // the first row slot's loads do not depend on phase A: issue them before it
-        RowSlot<NR> cur, nxt;
-        load_row_slot<NR>(cur, M, 0, ti, tj, D, DD);
 
         if (do_step) {
             // ---------------- phase A ----------------
@@ -276,18 +254,28 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         cplx m[NR][NR];
 #pragma unroll
         for (int ra = 0; ra < NR; ++ra) {
-            if (ra + 1 < NR) load_row_slot<NR>(nxt, M, ra + 1, ti, tj, D, DD);
             const int a = 16 * ra + ti;
             const bool rowok = a < D;
             const int al = a & 63;
             const double p11 = prop[al], p12 = prop[64 + al], p21 = prop[128 + al], p22 = prop[192 + al];
             const double sta = scl[al], ista = scl[64 + al];
+            double vqq[NR], vqp[NR], vpq[NR], vpp[NR];
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
                 const int b = 16 * rb + tj;
                 const bool ok = rowok && b < D;
                 const int e = a * D + b;
-                double mqq = cur.qq[rb], mqp = cur.qp[rb], mpq = cur.pq[rb], mpp = cur.pp[rb];
+                vqq[rb] = ok ? M[e] : 0.0;
+                vqp[rb] = ok ? M[DD + e] : 0.0;
+                vpq[rb] = ok ? M[2 * DD + e] : 0.0;
+                vpp[rb] = ok ? M[3 * DD + e] : 0.0;
+            }
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) {
+                const int b = 16 * rb + tj;
+                const bool ok = rowok && b < D;
+                const int e = a * D + b;
+                double mqq = vqq[rb], mqp = vqp[rb], mpq = vpq[rb], mpp = vpp[rb];
                 if (do_step) {
                     const double nqq = fma(p12, mpq, p11 * mqq), npq = fma(p22, mpq, p21 * mqq);
                     const double nqp = fma(p12, mpp, p11 * mqp), npp = fma(p22, mpp, p21 * mqp);
@@ -300,21 +288,28 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                                         0.5 * (-SC_HBAR * sta * sib * mqp + (1.0 / SC_HBAR) * ista * isib * mpq))
                                : c_make(0.0, 0.0);
             }
-            cur = nxt;
-            __asm__ volatile("" ::: "memory");   // keep at most two row slots of loads in flight (register budget)
         }
 
         // ---------------- phase C: determinant in registers ----------------
         cplx det = c_make(1.0, 0.0);
         unsigned long long done = 0ull;
         bool singular = false;
+        Stamps st;
+#ifdef SC_STAMPS
+        for (int i = 0; i < 16; ++i) st.acc[i] = 0;
+        st.last = 0; st.base = 0;
+#endif
         if (!(A.mode & 0x100)) {                 // 0x100: debug, skip the elimination (SC_DEBUG_SKIP_LU)
-            bool ok = eliminate_block<NR, 0>(m, det, done, D, rowbuf, pivrec, permseq, &weak);
-            if (NR > 1 && ok) ok = eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak);
-            if (NR > 2 && ok) ok = eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak);
-            if (NR > 3 && ok) ok = eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak);
+            bool ok = eliminate_block<NR, 0>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
+            if (NR > 1 && ok) ok = eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
+            if (NR > 2 && ok) ok = eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
+            if (NR > 3 && ok) ok = eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
             singular = !ok;
         }
+#ifdef SC_STAMPS
+        if (blockIdx.x == 0 && (tid & 63) == 0)
+            for (int i = 0; i < 16; ++i) g_stamps[tid >> 6][i] = st.acc[i];
+#endif
         __syncthreads();
         if (tid == 0 && weak && A.st.flags && !(A.mode & 0x100)) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
