@@ -44,7 +44,20 @@ def algorithmic_bytes_per_traj_step(D):
     return 64 * D * D + 64 * D + 72
 
 
-def cpu_baseline(omega, chi, nac, q0, dt, n=1000, nt=4):
+def profiled_traffic(n, dim):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/), if they match this workload"""
+    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t["workload"]["ntraj"] == n and t["workload"]["dim"] == dim:
+            return t["traffic_bytes_per_launch"], "profiles/r1_hbm_traffic.json (FETCH_SIZE calibrated + WRITE_SIZE, separate passes)"
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
+def cpu_baseline(omega, chi, nac, q0, dt, n=2000, nt=4):
     """the CPU oracle (torch eager restatement of the reference's op sequence) on a bounded sample"""
     from oracle import sc_oracle as orc
     # the GPU box gives one GPU's share of the host: 16 cores (oversubscribing the visible CPUs stalls torch)
@@ -128,6 +141,7 @@ def main():
         kern_ms = float(np.mean(step_ms))
         abytes = algorithmic_bytes_per_traj_step(dim) * n
         achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_source = profiled_traffic(n, dim)
         out = {
             "metric": "trajectory-steps/sec + wall-time to converged C(t), anharmonic-AS D=60",
             "value": n * world * K / wall, "unit": "trajectory-steps/s",
@@ -138,7 +152,7 @@ def main():
                        "trajectories_per_gpu": n, "trajectories_total": n * world, "dim": dim,
                        "sharding": f"{world} x {n} trajectories, one all-reduce of 4*K doubles per flush"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "hk_step_sd_kernel<4,4>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes},
             "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],

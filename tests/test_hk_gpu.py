@@ -122,3 +122,50 @@ def test_wrong_dimension_asserts():
     pot = engine_potential(cases.load("hk_1d"))
     with pytest.raises(AssertionError, match="potential has wrong dimensions"):
         prop.step(pot, 0.1)
+
+
+def _prefactor_of_state(name, make_blocks):
+    """c2 of the HIP engine and of the oracle for a hand-made monodromy state"""
+    from tests.engine_cases import engine_propagator
+    g = cases.load(name)
+    prop = engine_propagator(g)
+    ref = cases.oracle_propagator(g)
+    d, n = prop.dim, prop.ntraj
+    y = ref.y.clone()
+    blocks = make_blocks(d, n)
+    for k, blk in enumerate(blocks):
+        y[2 * d + k * d * d: 2 * d + (k + 1) * d * d] = blk.reshape(d * d, n)
+    ref.y = y
+    ref._prefactor()
+    prop.y = y.cuda()
+    prop._prefactor_initial()
+    torch.cuda.synchronize()
+    return cnp(prop._c2), ref.c2.numpy(), prop
+
+
+def test_dense_monodromy_through_fast_path():
+    """random dense (non-diagonal) monodromy blocks: the register elimination really has to pivot"""
+    torch.manual_seed(5)
+
+    def blocks(d, n):
+        eye = torch.eye(d).unsqueeze(2)
+        return [eye + 0.3 * torch.randn(d, d, n), 0.3 * torch.randn(d, d, n),
+                0.3 * torch.randn(d, d, n), eye + 0.3 * torch.randn(d, d, n)]
+    for name in ("hk_as60", "hk_as5_chi002"):
+        got, want, prop = _prefactor_of_state(name, blocks)
+        assert np.max(np.abs(got - want) / np.abs(want)) < 1e-10
+        assert int(prop._flags.sum().item()) == 0
+
+
+def test_weak_pivot_fallback():
+    """monodromy blocks = cyclic shift by 20 columns: every in-block pivot candidate is zero, so the fast path
+    must hand the trajectory to the fully pivoted elimination (and clear its flag afterwards)"""
+    def blocks(d, n):
+        shift = torch.roll(torch.eye(d), 20, dims=1).unsqueeze(2).expand(-1, -1, n).clone()
+        shift = shift * (1.0 + 0.1 * torch.rand(d, d, n))
+        zero = torch.zeros(d, d, n)
+        return [shift, zero, zero, shift.clone()]
+    got, want, prop = _prefactor_of_state("hk_as60", blocks)
+    assert np.all(np.abs(want) > 0)
+    assert np.max(np.abs(got - want) / np.abs(want)) < 1e-10
+    assert int(prop._flags.sum().item()) == 0

@@ -1,0 +1,125 @@
+"""CPU-only checks of the host side: setup algebra against the reference's golden intermediates, the
+C-ABI library (loads, exports every symbol of include/semiclassical_hip.h -- no compute calls), readers."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+torch.set_default_dtype(torch.float64)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["hk_as5_chi002", "hk_methylium", "hk_1d"])
+def test_sampling_matrices_match_reference(name):
+    from semiclassical_amd import hostmath
+    g = cases.load(name)
+    U, iGi0, iLz, detLz, dprime = hostmath.sampling_matrices(cases.T(g["Gamma_i"]), cases.T(g["Gamma_0"]))
+    assert cases.rel_err(U.numpy(), g["U"]) < 1e-14
+    assert cases.rel_err(iGi0.numpy(), g["iGi0"]) < 1e-13
+    assert dprime == g["U"].shape[1]
+
+
+def test_prefactor_constants_reproduce_reference_matrix():
+    """1/2[L1 Mqq R1 + L2 Mpp R2 - i L1 Mqp R2 + i L2 Mpq R1] == U^T mat U of the reference (via the oracle)"""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import hostmath
+    g = cases.load("hk_methylium")
+    Gi, Gt = cases.T(g["Gamma_i"]), cases.T(g["Gamma_t"])
+    pre = hostmath.PrefactorConstants(Gi, Gt, cases.T(g["U"]))
+    assert not pre.diag and pre.dprime == 6
+    ref = cases.oracle_propagator(g)
+    ref.y = cases.T(g["y_10"])
+    ref._prefactor()
+    Mqq, Mqp, Mpq, Mpp = (X[:, :, 3].type(torch.complex128) for X in ref.monodromy_matrices())
+    mat = 0.5 * (pre.L1 @ Mqq @ pre.R1 + pre.L2 @ Mpp @ pre.R2
+                 - 1j * pre.L1 @ Mqp @ pre.R2 + 1j * pre.L2 @ Mpq @ pre.R1)
+    assert abs(torch.linalg.det(mat) - ref.c2[3]) / abs(ref.c2[3]) < 1e-10
+
+
+def test_diag_detection():
+    from semiclassical_amd import hostmath
+    g = cases.load("hk_as5_chi002")
+    pre = hostmath.PrefactorConstants(cases.T(g["Gamma_i"]), cases.T(g["Gamma_t"]), cases.T(g["U"]))
+    assert pre.diag and torch.allclose(pre.st ** 2, torch.diagonal(cases.T(g["Gamma_t"])))
+    oc = hostmath.OverlapConstants(cases.T(g["Gamma_t"]), cases.T(g["Gamma_0"]))
+    assert oc.diag and oc.rank == 5
+
+
+def test_overlap_constants_match_oracle():
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import hostmath
+    g = cases.load("hk_methylium")
+    Gt, G0 = cases.T(g["Gamma_t"]), cases.T(g["Gamma_0"])
+    oc, ref = hostmath.OverlapConstants(Gt, G0), orc.OverlapOracle(Gt, G0)
+    assert not oc.diag and oc.rank == 6
+    assert torch.equal(oc.A, ref.Gi_iGij_Gj) and torch.equal(oc.B, ref.iGij) and torch.equal(oc.C, ref.Gj_iGij)
+    assert abs(oc.fac - float(ref.fac)) < 1e-15
+
+
+def test_time_grid_accumulates_like_the_reference():
+    from semiclassical_amd import hostmath
+    dt = 0.1
+    t, ref = 0.0, []
+    for _ in range(50):
+        ref.append(t)
+        t += dt
+    assert np.array_equal(hostmath.time_grid(50, dt), np.array(ref))
+    assert hostmath.time_grid(50, dt)[30] != 30 * dt        # the accumulated sum is not k*dt
+
+
+def test_library_exports_every_declared_symbol():
+    """every function declared in include/semiclassical_hip.h is exported by the shared library"""
+    header = open(os.path.join(ROOT, "include", "semiclassical_hip.h")).read()
+    declared = set(re.findall(r"\b(sc_[a-z_0-9]+)\s*\(", header))
+    from semiclassical_amd import _lib
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), name
+    assert _lib.lib.sc_version() >= 1
+    # struct sizes agree with the C layout (LP64): a mismatch would shift every pointer
+    assert ctypes.sizeof(_lib.sc_state) == 8 + 4 + 4 + 6 * 8
+    assert ctypes.sizeof(_lib.sc_potential) == 4 + 4 + 3 * 8 + 8 + 8
+    assert ctypes.sizeof(_lib.sc_hk_consts) == 16 + 6 * 8
+    assert ctypes.sizeof(_lib.sc_overlap_consts) == 8 + 5 * 8 + 8
+    assert ctypes.sizeof(_lib.sc_nac_consts) == 8 + 4 * 8 + 16
+
+
+def test_no_cpu_path():
+    from semiclassical_amd import propagators as PR
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        PR.HermanKlukPropagator(torch.eye(2), torch.eye(2), device="cpu")
+
+
+def test_potential_torch_protocol_matches_oracle():
+    """harmonic_approximation of the API classes (used outside the hot loop) == oracle potentials"""
+    from semiclassical_amd import potentials as P
+    from tests.engine_cases import engine_potential
+    for name in ("hk_as5_chi002", "hk_as5_chi000", "hk_methylium", "hk_1d"):
+        g = cases.load(name)
+        pot, ref = engine_potential(g), cases.oracle_potential(g)
+        r = torch.from_numpy(g["zi"][:pot.dimensions(), :7].copy())
+        for a, b in zip(pot.harmonic_approximation(r), ref.harmonic_approximation(r)):
+            assert torch.allclose(a, b, rtol=1e-14, atol=1e-300)
+        assert torch.equal(pot.derivative_coupling_1st(r), ref.derivative_coupling_1st(r))
+
+
+def test_fchk_reader_methylium():
+    """zero-point energy, rank of Gamma_0 and adiabatic gap quoted in SURVEY.md section 8c"""
+    ref_dir = "/root/reference/tests/DATA/examples/methylium_AH"
+    if not os.path.isdir(ref_dir):
+        pytest.skip("reference data not present on this machine")
+    from semiclassical_amd import units
+    from semiclassical_amd.readers import FormattedCheckpointFile
+    with open(os.path.join(ref_dir, "opt_freq_s1.fchk")) as f:
+        s1 = FormattedCheckpointFile(f)
+    x0, G0, ezpt = s1.vibrational_groundstate()
+    assert abs(ezpt - 0.0247324) < 1e-6
+    assert np.linalg.matrix_rank(G0, tol=1e-8) == 6
+    g = cases.load("hk_methylium")
+    assert cases.rel_err(G0, g["Gamma_0"]) < 1e-12 and cases.rel_err(x0, g["q0"]) < 1e-15
