@@ -100,6 +100,26 @@ typedef struct sc_nac_consts {
     double p0n1, n2;
 } sc_nac_consts;
 
+/* constants and per-trajectory tracker state of the Walton-Manolopoulos prefactor, reference
+ * propagators.py:1102-1130 (_prepare), :1195-1389 (_prefactor).  e = 2 d'.
+ *   U     D x d' (real)      eigenvectors of Gamma_0 + Gamma_i with non-zero eigenvalue      :495-498
+ *   Gt, G0, iGi0, S = iGi0.G0, Cqq = G0 - G0.iGi0.G0                     D x D real          :1280-1296
+ *   Cst   e x e complex = U2^T (2 filinov + Eqz^T Gi Eqz - 2i/hbar Epz^T Eqz) U2            :1227-1238
+ *   Bq    D x e complex = [Gi U, -i/hbar U]                                                  :1264
+ *   n1 = -hbar^2 tau1/m, s_n1 = S n1, w_n1 = G0 n1 (NULL until the potential is known)       :1693
+ *   inv_scale_a = 1/(2 sqrt(alpha beta))   :1328       inv_two_pi = 1/(2 pi)   :1358
+ *   pre = detG0^1/2 detGt^1/4 detGi^1/4 / sqrt(detGi0) with the pi-absorbing determinants    :1116-1125, 1598-1599
+ *   detA, detM [n] complex + sgnA, sgnM [n]: "previous" values and branch signs of the two trackers :1336, 1389 */
+typedef struct sc_wm_consts {
+    int32_t dim, dprime;
+    const double *U, *Gt, *G0, *iGi0, *S, *Cqq;
+    const double *Cst, *Bq;
+    const double *q0, *p0;
+    const double *n1, *s_n1, *w_n1;
+    double inv_scale_a, inv_two_pi, pre, p0n1, n2;
+    double *detA, *detM, *sgnA, *sgnM;
+} sc_wm_consts;
+
 int         sc_version(void);
 const char *sc_last_error(void);
 
@@ -142,6 +162,19 @@ int sc_hk_correlate(const sc_state *st, const sc_overlap_consts *ovl_t0, const s
  * Deterministic (fixed summation order).  Either partial buffer may be NULL (its slots are left untouched). */
 int sc_reduce_slot(const double *corr_partials, int32_t n_corr, const double *energy_partials, int32_t n_energy_blocks,
                    double n_energy, double *slot, void *stream);
+
+/* Walton-Manolopoulos: Filinov matrix A (eqn 50), its inverse and determinant, Gt/Gti/CQQ/M (57-78), the second
+ * inverse and determinant, the trackers of sqrt(detA), sqrt(detM) and the per-trajectory terms of eqns (85), (100),
+ * fused per trajectory.  Replaces WaltonManolopoulosPropagator._expand_L/_prefactor/autocorrelation_qp/
+ * autocorrelation/ic_correlation (propagators.py:1132-1389, 1577-1719) after sc_hk_step has advanced the state.
+ *   track: 2 initialise the trackers (t = 0), 1 track against the previous step, 0 recompute with the stored signs
+ *   has_nac == 0: k_ic terms are skipped (wc->n1 etc. may be NULL)
+ *   cq_out/kq_out complex [n] may be NULL; partials[sc_wm_grid()][4] as in sc_hk_correlate.
+ * Limits: every matrix of one trajectory lives in LDS, D <= ~24 at full rank (SC_ERR_UNSUPPORTED beyond). */
+int sc_wm_grid(int64_t n, int32_t dim);
+int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi, const double *probi,
+                    double mc_norm, int32_t track, int32_t has_nac, double *cq_out, double *kq_out,
+                    double *partials, void *stream);
 
 /* Energy-conservation guard on the device, reference propagators.py:385-398 (check_energy_conservation).
  * elog[4] = { <T+V>(t-dt), <T+V>(t), largest |change| seen so far, number of steps logged }.

@@ -42,6 +42,17 @@ class sc_nac_consts(C.Structure):
                 ("p0n1", C.c_double), ("n2", C.c_double)]
 
 
+class sc_wm_consts(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("dprime", C.c_int32),
+                ("U", c_double_p), ("Gt", c_double_p), ("G0", c_double_p), ("iGi0", c_double_p),
+                ("S", c_double_p), ("Cqq", c_double_p), ("Cst", c_double_p), ("Bq", c_double_p),
+                ("q0", c_double_p), ("p0", c_double_p),
+                ("n1", c_double_p), ("s_n1", c_double_p), ("w_n1", c_double_p),
+                ("inv_scale_a", C.c_double), ("inv_two_pi", C.c_double), ("pre", C.c_double),
+                ("p0n1", C.c_double), ("n2", C.c_double),
+                ("detA", c_double_p), ("detM", c_double_p), ("sgnA", c_double_p), ("sgnM", c_double_p)]
+
+
 SC_POT_MORSE, SC_POT_HARMONIC_SEP, SC_POT_EPS_MORSE, SC_POT_HARMONIC_DENSE = 1, 2, 3, 4
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
@@ -60,6 +71,9 @@ SIGNATURES = {
     "sc_hk_correlate": (C.c_int, [P(sc_state), P(sc_overlap_consts), P(sc_nac_consts), c_double_p, c_double_p,
                                   c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     "sc_energy_guard": (C.c_int, [c_double_p, C.c_int32, C.c_double, c_double_p, C.c_void_p]),
+    "sc_wm_grid": (C.c_int, [C.c_int64, C.c_int32]),
+    "sc_wm_correlate": (C.c_int, [P(sc_state), P(sc_wm_consts), c_double_p, c_double_p, C.c_double, C.c_int32,
+                                  C.c_int32, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     "sc_reduce_slot": (C.c_int, [c_double_p, C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p,
                                  C.c_void_p]),
 }

@@ -1,0 +1,370 @@
+// Walton-Manolopoulos prefactor and per-trajectory correlation terms, fused per trajectory.
+//
+// One workgroup per trajectory (grid-stride); every matrix of the trajectory lives in LDS.  Called after the HK step
+// kernel, which has already advanced (q, p, S, M) and tracked sqrt(c2).  Reference semantics reproduced
+// (paths relative to the reference repository, equation numbers of Walton & Manolopoulos 1996 as cited there):
+//   _expand_L        semiclassical/propagators.py:1132-1193   grad / Hessian of i/hbar S
+//   _prefactor       semiclassical/propagators.py:1195-1389   A (50), BQ Bq b0 (53-55), Gt Gti (57-59), CQQ CqQ PIq PIQ eps
+//                                                             (69-74), M (78), R.. P. gamma (79-84), trackers of detA, detM
+//   autocorrelation_qp  :1577-1614  eqn (85)      ic_correlation  :1652-1719  eqn (100)
+//
+// Restatement used here (all contractions are exact rewrites; differences are re-association only):
+//   * everything is carried in the projected space e = 2d':  Mq' = [Mqq U, Mqp U], Mp' = [Mpq U, Mpp U]  (D x e, real)
+//       A' = Cst' + Mq'^T Gt_w Mq' + i/hbar (2G - H),   G = Mp'^T Mq',  H[i][j] = i < d' ? G[i][j] : G[j][i]
+//       Cst' = 2 blockdiag(alpha U^T G0 U, beta U^T G0^+ U) + blockdiag(U^T Gi U, 0) - 2i/hbar [[0,0],[1,0]]      (host)
+//     the reference's b0 (55) is identically zero analytically (its two terms are the same contraction), so
+//     pi_t = P and pi_i = p;
+//   * A'/(2 sqrt(alpha beta)) and M'/(2 pi) are inverted by Gauss-Jordan with partial pivoting, which also yields the
+//     determinants detA, detM the reference takes of the same scaled matrices (:1328-1332, 1358-1359);
+//   * Rqq, RQQ, RqQ, Pq, PQ are never formed: eqn (85)/(100) only need their contractions with dq = q0-q, dQ = q0-Q and
+//     n1, i.e. bilinear forms a^T iM b with a, b in { CqQ^T dq, CqQ^T n1, G0 dQ, G0 n1, PIQ - p0 }.
+#include "sc_common.h"
+
+namespace {
+
+struct WmArgs {
+    sc_state st;
+    sc_wm_consts wc;
+    const double *zi, *probi;
+    double mc_norm;
+    int track;          // 0: use the stored branch signs, 1: track against the previous determinants, 2: initialise
+    int has_nac;
+    double *cq_out, *kq_out, *partials;
+};
+
+// Gauss-Jordan inversion of the n x n complex matrix in the left half of aug (n x 2n, row-major); the right half must
+// hold the identity on entry and holds the inverse on exit.  Returns det(left) to every thread.  colbuf: n complex.
+__device__ cplx lds_gauss_jordan(cplx *aug, int n, cplx *colbuf, int *ipiv) {
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, w2 = 2 * n;
+    cplx det = c_make(1.0, 0.0);
+    for (int k = 0; k < n; ++k) {
+        if (tid < 64) {
+            double best = -1.0;
+            int bi = k;
+            for (int i = k + lane; i < n; i += 64) {
+                const double m = c_abs2(aug[i * w2 + k]);
+                if (m > best) { best = m; bi = i; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (bi != k) {
+                for (int j = lane; j < w2; j += 64) {
+                    const cplx t = aug[k * w2 + j];
+                    aug[k * w2 + j] = aug[bi * w2 + j];
+                    aug[bi * w2 + j] = t;
+                }
+            }
+            if (lane == 0) *ipiv = bi;
+        }
+        __syncthreads();
+        const cplx piv = aug[k * w2 + k];
+        det = c_mul(det, piv);
+        if (*ipiv != k) det = c_make(-det.x, -det.y);
+        if (piv.x == 0.0 && piv.y == 0.0) { __syncthreads(); return c_make(0.0, 0.0); }
+        const cplx inv = c_inv(piv);
+        for (int i = tid; i < n; i += nth) colbuf[i] = aug[i * w2 + k];
+        __syncthreads();
+        for (int j = tid; j < w2; j += nth) aug[k * w2 + j] = c_mul(aug[k * w2 + j], inv);
+        __syncthreads();
+        for (int e = tid; e < n * w2; e += nth) {
+            const int i = e / w2, j = e - i * w2;
+            if (i != k) aug[e] = c_fnma(colbuf[i], aug[k * w2 + j], aug[e]);
+        }
+        __syncthreads();
+    }
+    return det;
+}
+
+// branch tracker of sqrt(z(t)), reference propagators.py:1006-1052; returns the sign to use now
+__device__ __forceinline__ double track_sign(int track, cplx z, cplx *prev, double *sgn) {
+    double s = *sgn;
+    if (track == 2) { s = 1.0; *sgn = s; *prev = z; }
+    else if (track == 1) {
+        const cplx z1 = *prev;
+        if (z1.x < 0.0 && z.x < 0.0 && z1.y * z.y < 0.0) s = -s;
+        *sgn = s; *prev = z;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
+    extern __shared__ double2 smem2[];
+    __shared__ double red[32];
+    __shared__ int ipiv;
+    const int D = A.st.dim, dp = A.wc.dprime, E = 2 * dp, DD = D * D, tid = threadIdx.x, nth = blockDim.x;
+    const sc_wm_consts &W = A.wc;
+
+    // ---- LDS carve-up ----
+    double *f = (double *)smem2;
+    double *Mq = f;              f += D * E;        // Mq' (D x E)
+    double *Mp = f;              f += D * E;        // Mp'
+    double *Tq = f;              f += D * E;        // Gamma_t Mq'
+    double *G = f;               f += E * E;        // Mp'^T Mq'
+    double *vec = f;             f += 8 * D;        // dq, dQ, dp, g, s_dq, w_dQ, (2 spare)
+    f += ((f - (double *)smem2) & 1);               // 16-byte alignment of the complex arrays
+    cplx *c = (cplx *)f;
+    cplx *aug = c;               c += E * 2 * E;    // [A'/s | I] -> [I | s iA']
+    cplx *BQ = c;                c += D * E;
+    cplx *Wm = c;                c += D * E;        // BQ' iA'
+    cplx *Gt = c;                c += DD;           // Gt, later CQQ
+    cplx *Gti = c;               c += DD;
+    cplx *V = c;                 c += DD;           // Gti iGi0
+    cplx *augM = c;              c += dp * 2 * dp;  // [M'/(2pi) | I]
+    cplx *colbuf = c;            c += E > D ? E : D;
+    cplx *cv = c;                c += 5 * D;        // u_dq, u_n1, w_dQ(c), w_n1(c), y
+    cplx *hat = c;               c += 5 * dp;       // U^T of the five vectors
+    cplx *rho = c;               c += 5 * dp;       // iM' of them
+
+    const cplx *Cst = (const cplx *)W.Cst, *Bq = (const cplx *)W.Bq;
+    const double ihb = 1.0 / SC_HBAR;
+    double acc[4] = {0, 0, 0, 0};
+
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        const double *qp = A.st.qp + tr * 2 * D, *zi = A.zi + tr * 2 * D;
+        const double *M = A.st.mono + tr * 4 * (int64_t)DD;
+        __syncthreads();
+        // Mq' = [Mqq U, Mqp U], Mp' = [Mpq U, Mpp U]; per-trajectory vectors
+        for (int e = tid; e < D * E; e += nth) {
+            const int a = e / E, j = e - a * E, blk = j >= dp, jj = blk ? j - dp : j;
+            const double *Mqx = M + (blk ? DD : 0) + a * D, *Mpx = M + (blk ? 3 * DD : 2 * DD) + a * D;
+            double sq = 0.0, sp = 0.0;
+            for (int b = 0; b < D; ++b) { const double u = W.U[b * dp + jj]; sq = fma(Mqx[b], u, sq); sp = fma(Mpx[b], u, sp); }
+            Mq[e] = sq; Mp[e] = sp;
+        }
+        for (int a = tid; a < D; a += nth) {
+            vec[a] = W.q0[a] - zi[a];                 // dq
+            vec[D + a] = W.q0[a] - qp[a];             // dQ
+            vec[2 * D + a] = W.p0[a] - zi[D + a];     // dp = p0 - p_initial
+        }
+        __syncthreads();
+        // Tq = Gamma_t Mq' ; G = Mp'^T Mq' ; g = iGi0 dp ; s_dq = S dq ; w_dQ = G0 dQ
+        for (int e = tid; e < D * E; e += nth) {
+            const int a = e / E, j = e - a * E;
+            double s = 0.0;
+            for (int b = 0; b < D; ++b) s = fma(W.Gt[a * D + b], Mq[b * E + j], s);
+            Tq[e] = s;
+        }
+        for (int e = tid; e < E * E; e += nth) {
+            const int i = e / E, j = e - i * E;
+            double s = 0.0;
+            for (int a = 0; a < D; ++a) s = fma(Mp[a * E + i], Mq[a * E + j], s);
+            G[e] = s;
+        }
+        for (int a = tid; a < D; a += nth) {
+            double g = 0.0, s = 0.0, w = 0.0;
+            for (int b = 0; b < D; ++b) {
+                g = fma(W.iGi0[a * D + b], vec[2 * D + b], g);
+                s = fma(W.S[a * D + b], vec[b], s);
+                w = fma(W.G0[a * D + b], vec[D + b], w);
+            }
+            vec[3 * D + a] = g; vec[4 * D + a] = s; vec[5 * D + a] = w;
+        }
+        __syncthreads();
+        // A'/s with s = 2 sqrt(alpha beta), identity on the right; BQ' = Tq + i/hbar Mp'
+        for (int e = tid; e < E * E; e += nth) {
+            const int i = e / E, j = e - i * E;
+            double s = 0.0;
+            for (int a = 0; a < D; ++a) s = fma(Mq[a * E + i], Tq[a * E + j], s);
+            const double h = (i < dp) ? G[i * E + j] : G[j * E + i];
+            const cplx a0 = Cst[e];
+            aug[i * 2 * E + j] = c_make((a0.x + s) * W.inv_scale_a, (a0.y + ihb * (2.0 * G[e] - h)) * W.inv_scale_a);
+            aug[i * 2 * E + E + j] = c_make(i == j ? 1.0 : 0.0, 0.0);
+        }
+        for (int e = tid; e < D * E; e += nth) BQ[e] = c_make(Tq[e], ihb * Mp[e]);
+        __syncthreads();
+        const cplx detA = lds_gauss_jordan(aug, E, colbuf, &ipiv);
+        // Wm = BQ' iA' (iA' = inverse(A'/s)/s)
+        for (int e = tid; e < D * E; e += nth) {
+            const int a = e / E, j = e - a * E;
+            cplx s = c_make(0, 0);
+            for (int k = 0; k < E; ++k) s = c_fma(BQ[a * E + k], aug[k * 2 * E + E + j], s);
+            Wm[e] = c_scale(s, W.inv_scale_a);
+        }
+        __syncthreads();
+        // Gt = Gamma_t - Wm BQ'^T (57) ; Gti = Wm Bq'^T (59)
+        for (int e = tid; e < DD; e += nth) {
+            const int a = e / D, b = e - a * D;
+            cplx s = c_make(0, 0), t = c_make(0, 0);
+            for (int j = 0; j < E; ++j) {
+                s = c_fma(Wm[a * E + j], BQ[b * E + j], s);
+                t = c_fma(Wm[a * E + j], Bq[b * E + j], t);
+            }
+            Gt[e] = c_make(W.Gt[e] - s.x, -s.y);
+            Gti[e] = t;
+        }
+        __syncthreads();
+        // V = Gti iGi0 ; y = (P - p0) + Gti g ; u_dq = Gti s_dq ; u_n1 = Gti s_n1 ; w vectors as complex
+        for (int e = tid; e < DD; e += nth) {
+            const int a = e / D, b = e - a * D;
+            cplx s = c_make(0, 0);
+            for (int k = 0; k < D; ++k) { const double x = W.iGi0[k * D + b]; s.x = fma(Gti[a * D + k].x, x, s.x); s.y = fma(Gti[a * D + k].y, x, s.y); }
+            V[e] = s;
+        }
+        for (int a = tid; a < D; a += nth) {
+            cplx y = c_make(qp[D + a] - W.p0[a], 0.0), u1 = c_make(0, 0), u2 = c_make(0, 0);
+            for (int b = 0; b < D; ++b) {
+                const cplx gt = Gti[a * D + b];
+                const double g = vec[3 * D + b], s1 = vec[4 * D + b], s2 = A.has_nac ? W.s_n1[b] : 0.0;
+                y.x = fma(gt.x, g, y.x); y.y = fma(gt.y, g, y.y);
+                u1.x = fma(gt.x, s1, u1.x); u1.y = fma(gt.y, s1, u1.y);
+                u2.x = fma(gt.x, s2, u2.x); u2.y = fma(gt.y, s2, u2.y);
+            }
+            cv[a] = u1; cv[D + a] = u2;
+            cv[2 * D + a] = c_make(vec[5 * D + a], 0.0);
+            cv[3 * D + a] = c_make(A.has_nac ? W.w_n1[a] : 0.0, 0.0);
+            cv[4 * D + a] = y;
+        }
+        __syncthreads();
+        // CQQ = Gt - V Gti^T (70), in place in Gt
+        for (int e = tid; e < DD; e += nth) {
+            const int a = e / D, b = e - a * D;
+            cplx s = c_make(0, 0);
+            for (int k = 0; k < D; ++k) s = c_fma(V[a * D + k], Gti[b * D + k], s);
+            Gt[e] = c_sub(Gt[e], s);         // each thread only touches its own element of Gt
+        }
+        __syncthreads();
+        // M'/(2 pi) = U^T (G0 + CQQ) U / (2 pi) ; identity on the right ; hat = U^T {5 vectors}
+        for (int e = tid; e < dp * dp; e += nth) {
+            const int i = e / dp, j = e - i * dp;
+            cplx s = c_make(0, 0);
+            for (int a = 0; a < D; ++a) {
+                cplx row = c_make(0, 0);
+                for (int b = 0; b < D; ++b) {
+                    const double u = W.U[b * dp + j];
+                    row.x = fma(W.G0[a * D + b] + Gt[a * D + b].x, u, row.x);
+                    row.y = fma(Gt[a * D + b].y, u, row.y);
+                }
+                const double ui = W.U[a * dp + i];
+                s.x = fma(ui, row.x, s.x); s.y = fma(ui, row.y, s.y);
+            }
+            augM[i * 2 * dp + j] = c_scale(s, W.inv_two_pi);
+            augM[i * 2 * dp + dp + j] = c_make(i == j ? 1.0 : 0.0, 0.0);
+        }
+        for (int e = tid; e < 5 * dp; e += nth) {
+            const int v = e / dp, i = e - v * dp;
+            cplx s = c_make(0, 0);
+            for (int a = 0; a < D; ++a) { const double u = W.U[a * dp + i]; s.x = fma(u, cv[v * D + a].x, s.x); s.y = fma(u, cv[v * D + a].y, s.y); }
+            hat[e] = s;
+        }
+        __syncthreads();
+        const cplx detM = lds_gauss_jordan(augM, dp, colbuf, &ipiv);
+        // rho_v = iM' hat_v,  iM' = inverse(M'/(2 pi)) / (2 pi)
+        for (int e = tid; e < 5 * dp; e += nth) {
+            const int v = e / dp, i = e - v * dp;
+            cplx s = c_make(0, 0);
+            for (int k = 0; k < dp; ++k) s = c_fma(augM[i * 2 * dp + dp + k], hat[v * dp + k], s);
+            rho[e] = c_scale(s, W.inv_two_pi);
+        }
+        __syncthreads();
+
+        // ---- scalars: one thread per trajectory is enough (O(d'^2 + D) work) ----
+        if (tid == 0) {
+            auto form = [&](int a, int b) {                       // a^T iM b
+                cplx s = c_make(0, 0);
+                for (int i = 0; i < dp; ++i) s = c_fma(hat[a * dp + i], rho[b * dp + i], s);
+                return s;
+            };
+            enum { UDQ = 0, UN1 = 1, WDQ = 2, WN1 = 3, Y = 4 };
+            double dqCdq = 0, dqCn1 = 0, dQGdQ = 0, dQGn1 = 0, piq_dq = 0, piq_n1 = 0, p0_dQ = 0, eps = 0;
+            for (int a = 0; a < D; ++a) {
+                double cdq = 0.0, cn1 = 0.0, g0g = 0.0;
+                for (int b = 0; b < D; ++b) {
+                    cdq = fma(W.Cqq[a * D + b], vec[b], cdq);
+                    if (A.has_nac) cn1 = fma(W.Cqq[a * D + b], W.n1[b], cn1);
+                    g0g = fma(W.G0[a * D + b], vec[3 * D + b], g0g);
+                }
+                const double piq = W.p0[a] - g0g;                                  // (72)
+                dqCdq = fma(vec[a], cdq, dqCdq);
+                dqCn1 = fma(vec[a], cn1, dqCn1);
+                dQGdQ = fma(vec[D + a], vec[5 * D + a], dQGdQ);
+                if (A.has_nac) { dQGn1 = fma(vec[D + a], W.w_n1[a], dQGn1); piq_n1 = fma(piq, W.n1[a], piq_n1); }
+                piq_dq = fma(piq, vec[a], piq_dq);
+                p0_dQ = fma(W.p0[a], vec[D + a], p0_dQ);
+                eps = fma(vec[2 * D + a], vec[3 * D + a], eps);
+            }
+            eps *= -0.5 * ihb * ihb;                                                // (74), b0 = 0
+            const cplx yy = form(Y, Y);
+            const cplx gamma = c_make(eps - 0.5 * ihb * ihb * yy.x, -0.5 * ihb * ihb * yy.y);   // (84)
+            const cplx q_rqq_q = c_sub(c_make(dqCdq, 0), form(UDQ, UDQ));
+            const cplx Q_rQQ_Q = c_sub(c_make(dQGdQ, 0), form(WDQ, WDQ));
+            const cplx q_rqQ_Q = form(UDQ, WDQ);
+            const cplx Pq_dq = c_sub(c_make(piq_dq, 0), form(UDQ, Y));
+            const cplx PQ_dQ = c_add(c_make(p0_dQ, 0), form(WDQ, Y));
+            cplx ex = gamma;
+            ex = c_sub(ex, c_scale(q_rqq_q, 0.5));
+            ex = c_sub(ex, c_scale(Q_rQQ_Q, 0.5));
+            ex = c_add(ex, q_rqQ_Q);
+            ex = c_add(ex, c_mul(c_make(0.0, -ihb), Pq_dq));
+            ex = c_add(ex, c_mul(c_make(0.0, ihb), PQ_dQ));
+            // branch-tracked square roots
+            cplx *prevA = (cplx *)A.wc.detA + tr, *prevM = (cplx *)A.wc.detM + tr;
+            const double sA = track_sign(A.track, detA, prevA, A.wc.sgnA + tr);
+            const double sM = track_sign(A.track, detM, prevM, A.wc.sgnM + tr);
+            const cplx cpre = c_scale(c_sqrt(((const cplx *)A.st.c2)[tr]), A.st.sgn[tr]);
+            cplx pre = c_mul(cpre, c_exp(c_make(0.0, A.st.act[tr] * ihb)));
+            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detA)), sA));
+            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detM)), sM));
+            const double w = W.pre / (A.mc_norm * A.probi[tr]);
+            const cplx cq = c_scale(c_mul(pre, c_exp(ex)), w);                      // (85) / (n P (2 pi hbar)^D)
+            acc[0] += cq.x; acc[1] += cq.y;
+            if (A.cq_out) ((cplx *)A.cq_out)[tr] = cq;
+            if (A.has_nac) {
+                const cplx nacqQ = form(UN1, WN1);
+                const cplx PQ_n1 = c_add(c_make(W.p0n1, 0), form(WN1, Y));
+                const cplx Pq_n1 = c_sub(c_make(piq_n1, 0), form(UN1, Y));
+                cplx nacQ = c_sub(c_make(dQGn1, 0), form(WDQ, WN1));                // dQ^T RQQ n1
+                nacQ = c_sub(nacQ, form(UDQ, WN1));                                 // - dq^T RqQ n1
+                nacQ = c_add(nacQ, c_mul(c_make(0.0, -ihb), PQ_n1));
+                nacQ.x += W.n2;
+                cplx nacq = c_sub(c_make(dqCn1, 0), form(UDQ, UN1));                // dq^T Rqq n1
+                nacq = c_sub(nacq, form(UN1, WDQ));                                 // - n1^T RqQ dQ
+                nacq = c_add(nacq, c_mul(c_make(0.0, ihb), Pq_n1));
+                nacq.x += W.n2;
+                cplx kq = c_mul(c_add(nacqQ, c_mul(nacQ, nacq)), cq);               // (100)
+                kq = c_scale(kq, ihb * ihb);
+                acc[2] += kq.x; acc[3] += kq.y;
+                if (A.kq_out) ((cplx *)A.kq_out)[tr] = kq;
+            }
+        }
+    }
+    (void)red;
+    if (tid == 0) for (int i = 0; i < 4; ++i) A.partials[(size_t)blockIdx.x * 4 + i] = acc[i];
+}
+
+size_t wm_lds_bytes(int D, int dp) {
+    const size_t E = 2 * (size_t)dp, DD = (size_t)D * D;
+    size_t doubles = 3 * D * E + E * E + 8 * D + 1;
+    size_t cplxs = E * 2 * E + 2 * D * E + 3 * DD + (size_t)dp * 2 * dp + (E > (size_t)D ? E : D) + 5 * D + 10 * dp;
+    return doubles * 8 + cplxs * 16 + 32;
+}
+
+}  // namespace
+
+extern "C" int sc_wm_grid(int64_t n, int32_t dim) {
+    (void)dim;
+    return (int)(n < 2048 ? (n > 0 ? n : 1) : 2048);
+}
+
+extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi, const double *probi,
+                               double mc_norm, int32_t track, int32_t has_nac, double *cq_out, double *kq_out,
+                               double *partials, void *stream) {
+    if (!st || !wc || !zi || !probi || !partials) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: null argument");
+    if (wc->dim != st->dim) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: dimension mismatch");
+    if (st->n <= 0) return SC_OK;
+    const size_t lds = wm_lds_bytes(st->dim, wc->dprime);
+    if (lds > 160 * 1024)
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_correlate: D=%d d'=%d needs %zu B of LDS per trajectory (limit 160 KiB)",
+                       st->dim, wc->dprime, lds);
+    WmArgs a;
+    a.st = *st; a.wc = *wc; a.zi = zi; a.probi = probi; a.mc_norm = mc_norm; a.track = track; a.has_nac = has_nac;
+    a.cq_out = cq_out; a.kq_out = kq_out; a.partials = partials;
+    if (hipFuncSetAttribute((const void *)wm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sc_check_launch("sc_wm_correlate (LDS attribute)");
+    const int threads = st->dim <= 16 ? 64 : 256;
+    hipLaunchKernelGGL(wm_kernel, dim3(sc_wm_grid(st->n, st->dim)), dim3(threads), lds, (hipStream_t)stream, a);
+    return sc_check_launch("sc_wm_correlate");
+}

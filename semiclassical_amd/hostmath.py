@@ -132,3 +132,38 @@ def time_grid(nt, dt):
         out[k] = t
         t += dt
     return out
+
+
+class WMConstants(object):
+    """constants of the Walton-Manolopoulos prefactor, reference propagators.py:1102-1130, 1227-1238, 1264, 1295
+
+    Everything is expressed in the projected space of dimension e = 2 d' (see csrc/sc_wm.hip).
+    """
+
+    def __init__(self, Gamma_0, Gamma_i, Gamma_t, iGi0, U, alpha, beta):
+        D, dp = U.shape
+        Ur = U.real.contiguous() if U.is_complex() else U
+        pdet = lambda G, s: torch.prod((lambda e: e[abs(e) > ZERO] / s)(_eigh(G)[0]))
+        detG0, detGi, detGt = pdet(Gamma_0, np.pi), pdet(Gamma_i, np.pi), pdet(Gamma_t, np.pi)
+        detGi0 = pdet(Gamma_0 + Gamma_i, 2 * np.pi)
+        self.pre = float(detG0 ** 0.5 * detGt ** 0.25 * detGi ** 0.25 / torch.sqrt(detGi0))     # :1598-1599
+        e0, V0 = _eigh(Gamma_0)
+        keep = e0 > ZERO
+        iGamma_0 = torch.einsum('ij,j,kj->ik', V0[:, keep], 1.0 / e0[keep], V0[:, keep])      # :1130
+        self.dim, self.dprime = D, dp
+        self.U = Ur.contiguous()
+        self.Gt, self.G0, self.iGi0 = Gamma_t.contiguous(), Gamma_0.contiguous(), iGi0.contiguous()
+        self.S = (iGi0 @ Gamma_0).contiguous()
+        self.Cqq = (Gamma_0 - Gamma_0 @ iGi0 @ Gamma_0).contiguous()                          # (69)
+        E = 2 * dp
+        Cst = torch.zeros((E, E), dtype=C128)
+        Cst[:dp, :dp] = 2 * alpha * (Ur.T @ Gamma_0 @ Ur) + Ur.T @ Gamma_i @ Ur
+        Cst[dp:, dp:] = 2 * beta * (Ur.T @ iGamma_0 @ Ur)
+        Cst[dp:, :dp] += -2j / hbar * (Ur.T @ Ur)
+        self.Cst = Cst.contiguous()
+        Bq = torch.zeros((D, E), dtype=C128)
+        Bq[:, :dp] = Gamma_i @ Ur
+        Bq[:, dp:] = -1j / hbar * Ur
+        self.Bq = Bq.contiguous()
+        self.inv_scale_a = 1.0 / (2.0 * math.sqrt(alpha * beta))
+        self.inv_two_pi = 1.0 / (2.0 * np.pi)

@@ -24,10 +24,10 @@ import numpy as np
 import torch
 
 from . import _lib, hostmath
-from ._lib import lib, check, ptr, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts
+from ._lib import lib, check, ptr, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts
 from .units import hbar
 
-__all__ = ['HermanKlukPropagator']
+__all__ = ['HermanKlukPropagator', 'WaltonManolopoulosPropagator']
 
 logger = logging.getLogger(__name__)
 
@@ -169,6 +169,7 @@ class HermanKlukPropagator(object):
     def _prefactor_initial(self):
         """prefactor at t = 0 and initialisation of the branch tracker (reference propagators.py:631)"""
         check(lib.sc_hk_step(_NULL_POT(self.dim), self._state, self._hk, 0.0, 1, None, self._stream()))
+        self._after_prefactor(track=2)
 
     # ------------------------------------------------------------------ time stepping
     def step(self, potential, dt):
@@ -192,6 +193,10 @@ class HermanKlukPropagator(object):
         check(lib.sc_energy_guard(ptr(self._epart), self._gstep, float(self.ntraj), ptr(self._elog), s))
         self._nsteps += 1
         self._remember_nac(potential)
+        self._after_prefactor(track=1)
+
+    def _after_prefactor(self, track):
+        """hook for propagators whose prefactor needs more than the HK determinant (WM)"""
 
     def _potential_descriptor(self, potential):
         if not hasattr(potential, "_descriptor"):
@@ -362,3 +367,95 @@ def C_void(address):
 def _NULL_POT(dim):
     """descriptor for prefactor-only launches (the potential is not touched in mode 1)"""
     return _lib.sc_potential(kind=_lib.SC_POT_HARMONIC_SEP, dim=dim)
+
+
+class WaltonManolopoulosPropagator(HermanKlukPropagator):
+    """Walton-Manolopoulos (Filinov-smoothed) propagator, reference propagators.py:1077-1719.
+
+    ``alpha``, ``beta``: widths of the phase-space cell over which the HK integrand is integrated out.
+    The Filinov matrix, its inverse / determinant, the second inverse / determinant and the terms of
+    eqns (85) and (100) are evaluated per trajectory by ``sc_wm_correlate`` right after the HK step kernel.
+    All matrices of one trajectory are held in LDS, which limits this round's kernel to D <~ 24 at full rank.
+    """
+
+    def __init__(self, Gamma_i, Gamma_t, alpha, beta, device='cuda'):
+        super().__init__(Gamma_i, Gamma_t, device=device)
+        self.alpha = torch.tensor(float(alpha))
+        self.beta = torch.tensor(float(beta))
+
+    def _prepare(self):
+        super()._prepare()
+        dev, n = self.device, self.ntraj
+        wm = hostmath.WMConstants(self._G0h, self._Gi, self._Gt, self._iGi0h, self.U.cpu(),
+                                  float(self.alpha), float(self.beta))
+        self._wm_host = wm
+        up = lambda x: x.contiguous().to(dev)
+        self._wm_bufs = {k: up(getattr(wm, k)) for k in ("U", "Gt", "G0", "iGi0", "S", "Cqq", "Cst", "Bq")}
+        self._detA = torch.ones(n, dtype=C128, device=dev)
+        self._detM = torch.ones(n, dtype=C128, device=dev)
+        self._sgnA = torch.ones(n, dtype=F64, device=dev)
+        self._sgnM = torch.ones(n, dtype=F64, device=dev)
+        self._gwm = lib.sc_wm_grid(n, self.dim)
+        self._wpart = torch.zeros((self._gwm, 4), dtype=F64, device=dev)
+        self._wm_step, self._wm_has_nac = -1, False
+        self._wm_nac_bufs = None
+        self._build_wm_struct()
+
+    def _build_wm_struct(self):
+        b, wm, nb = self._wm_bufs, self._wm_host, self._wm_nac_bufs
+        self._wm = sc_wm_consts(
+            dim=self.dim, dprime=wm.dprime, U=ptr(b["U"]), Gt=ptr(b["Gt"]), G0=ptr(b["G0"]), iGi0=ptr(b["iGi0"]),
+            S=ptr(b["S"]), Cqq=ptr(b["Cqq"]), Cst=ptr(b["Cst"]), Bq=ptr(b["Bq"]), q0=ptr(self.q0), p0=ptr(self.p0),
+            n1=ptr(nb[0]) if nb else None, s_n1=ptr(nb[1]) if nb else None, w_n1=ptr(nb[2]) if nb else None,
+            inv_scale_a=wm.inv_scale_a, inv_two_pi=wm.inv_two_pi, pre=wm.pre,
+            p0n1=self._wm_p0n1 if nb else 0.0, n2=self._wm_n2 if nb else 0.0,
+            detA=ptr(self._detA), detM=ptr(self._detM), sgnA=ptr(self._sgnA), sgnM=ptr(self._sgnM))
+
+    def _remember_nac(self, potential):
+        key = id(potential)
+        if self._nac_key == key:
+            return
+        super()._remember_nac(potential)
+        masses = hostmath.as_f64(potential.masses())
+        probe = torch.zeros((self.dim, 1), dtype=F64)
+        tau1 = hostmath.as_f64(potential.derivative_coupling_1st(probe))[:, 0]
+        tau2 = hostmath.as_f64(potential.derivative_coupling_2nd(probe))[:, 0]
+        n1 = -hbar ** 2 * tau1 / masses
+        wm = self._wm_host
+        dev = self.device
+        self._wm_nac_bufs = [n1.to(dev), (wm.S @ n1).to(dev), (wm.G0 @ n1).to(dev)]
+        self._wm_p0n1 = float(torch.dot(self._p0h, n1))
+        self._wm_n2 = float(-hbar ** 2 * 0.5 * torch.sum(tau2 / masses))
+        self._build_wm_struct()
+
+    def _wm_launch(self, track):
+        has_nac = self._wm_nac_bufs is not None
+        check(lib.sc_wm_correlate(self._state, self._wm, ptr(self._zi_t), ptr(self.probi), self._mc_norm(),
+                                  track, int(has_nac), ptr(self._cq), ptr(self._kq), ptr(self._wpart),
+                                  self._stream()))
+        self._wm_step, self._wm_has_nac = self._nsteps, has_nac
+
+    def _after_prefactor(self, track):
+        self._wm_launch(track)
+
+    def _launch_correlate(self, slot_ptr, per_trajectory=True):
+        # the per-trajectory terms were produced together with the prefactor; recompute (with the stored branch
+        # signs, no tracking) only if the coupling vector was not known at that time
+        if self._wm_step != self._nsteps or (self._wm_nac_bufs is not None and not self._wm_has_nac):
+            self._wm_launch(0)
+        check(lib.sc_reduce_slot(ptr(self._wpart), self._gwm, None, 0, 1.0, C_void(slot_ptr), self._stream()))
+
+    def _correlate_current(self, need_nac):
+        if self._corr_step == self._nsteps and (self._corr_has_nac or not need_nac):
+            return
+        self._launch_correlate(self._slot.data_ptr())
+        self._corr_step, self._corr_has_nac = self._nsteps, self._wm_has_nac
+        self._slot_host = self._slot.cpu().numpy().copy()
+        self._check_energy_guard()
+
+    def _get_signs_of_sqrt(self, key):
+        if key == "detA":
+            return self._sgnA.type(C128)
+        if key == "detM":
+            return self._sgnM.type(C128)
+        return super()._get_signs_of_sqrt(key)

@@ -1,0 +1,48 @@
+"""Parity of the HIP Walton-Manolopoulos path with the reference's golden vectors (through the C-ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8     # asserted; north_star requires 1e-6
+
+
+def cnp(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", cases.WM_CASES)
+def test_wm_matches_reference_golden(name):
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load(name)
+    pot = engine_potential(g)
+    prop = engine_propagator(g)
+    nt, dt, E0 = int(g["nt"]), float(g["dt"]), float(g["E0"])
+    cauto = np.zeros(nt, dtype=complex)
+    kic = np.zeros(nt, dtype=complex)
+    for t in range(nt):
+        assert cases.rel_err(cnp(prop._detA), g["detA"][t]) < TOL, f"detA at step {t}"
+        assert cases.rel_err(cnp(prop._detM), g["detM"][t]) < TOL, f"detM at step {t}"
+        cauto[t] = prop.autocorrelation(E0)
+        kic[t] = prop.ic_correlation(pot, E0)
+        prop.step(pot, dt)
+        step = t + 1
+        if step in g["snaps"]:
+            assert np.array_equal(cnp(prop._sgnA), g[f"signsA_{step}"].real)
+            assert np.array_equal(cnp(prop._sgnM), g[f"signsM_{step}"].real)
+            assert cases.rel_err(cnp(prop.autocorrelation_qp()), g[f"cauto_qp_{step}"]) < TOL
+    prop.synchronize()
+    assert cases.rel_err(cauto, g["cauto"]) < TOL
+    assert cases.rel_err(kic, g["kic"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["wm_methylium", "wm_as5_chi002"])
+def test_wm_fused_run(name):
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load(name)
+    prop = engine_propagator(g)
+    cauto, kic = prop.run(engine_potential(g), float(g["dt"]), int(g["nt"]), float(g["E0"]))
+    assert cases.rel_err(cauto, g["cauto"]) < TOL
+    assert cases.rel_err(kic, g["kic"]) < TOL
