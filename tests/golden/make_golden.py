@@ -197,3 +197,20 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def rates_golden():
+    """reference rates.rate_from_correlation on the golden k_ic(t) of hk_as5_chi002 (run after main())"""
+    from semiclassical import rates as R, broadening as B
+    g = dict(np.load(os.path.join(HERE, "hk_as5_chi002.npz")))
+    nt, dt = int(g["nt"]), float(g["dt"])
+    times = np.linspace(0.0, nt * dt, nt)
+    sigma = 0.01 / np.sqrt(2.0 * np.log(2.0)) / units.hartree_to_ev
+    en, rate = R.rate_from_correlation(times, g["kic"], B.gaussian(sigma))
+    _, rate2 = R.rate_from_correlation(times, g["kic"], B.lorentzian(1e-3))
+    np.savez_compressed(os.path.join(HERE, "rates_as5.npz"), times=times, kic=g["kic"], sigma=sigma, energies=en,
+                        rate=rate, gamma=1e-3, rate_lorentzian=rate2)
+
+
+if __name__ == "__main__":
+    rates_golden()
