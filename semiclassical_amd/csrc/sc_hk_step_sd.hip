@@ -113,53 +113,49 @@ __device__ __forceinline__ void eliminate(cplx (&m)[NR][NR], const cplx (&r)[NR]
     }
 }
 
-// all elimination steps of the diagonal block KB; returns false when a zero pivot was met
+// all elimination steps of the diagonal block KB; returns false when a zero pivot was met.
+// Within block KB only the columns of slot KB are consumed as pivots: `live` (per thread) says whether column
+// (slot KB, lane tj) is still available; slots rb > KB are untouched, slots rb < KB are finished.  Padded columns
+// (j >= D) hold zeros and can never win the magnitude search unless the whole row is zero (= singular).
 template <int NR, int KB>
-__device__ __forceinline__ bool eliminate_block(cplx (&m)[NR][NR], cplx &det, unsigned long long &done, int D,
-                                                cplx (*rowbuf)[64], PivotRecord *pivrec, int *permseq, int *weak,
-                                                Stamps &st) {
+__device__ __forceinline__ bool eliminate_block(cplx (&m)[NR][NR], cplx &det, int D, cplx (*rowbuf)[64],
+                                                PivotRecord *pivrec, int *permseq, int *weak, Stamps &st) {
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15, lane = tid & 63;
-    for (int kt = 0; kt < 16; ++kt) {
+    const int nk = min(16, D - 16 * KB);
+    bool live = 16 * KB + tj < D;
+    for (int kt = 0; kt < nk; ++kt) {
         const int k = 16 * KB + kt;
-        if (k >= D) break;
         const int par = k & 1;
 #ifdef SC_STAMPS
         st.base = ((tid >> 6) == (kt >> 2)) ? 0 : 8;      // owner wave of this step or not
         STAMP(st, 7);                                    // (restart the clock)
 #endif
         if (ti == kt) {
-            // key = upper 26 bits of |a_kj|^2 (as an integer) | (63 - j); in-block candidates and the rest of the row
-            int key_blk = -1, key_out = -1;
+            // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj); in-block candidates and the rest of the row
+            const int blk = (__double2hiint(c_abs2(m[KB][KB])) & ~15) | (15 - tj);
+            int key_blk = live ? blk : -1, key_out = -1;
 #pragma unroll
-            for (int rb = KB; rb < NR; ++rb) {
-                const int j = 16 * rb + tj;
-                const int cand = (__double2hiint(c_abs2(m[KB][rb])) & ~63) | (63 - j);
-                const bool live = j < D && !((done >> j) & 1ull);
-                if (rb == KB) key_blk = live ? cand : -1;
-                else key_out = max(key_out, live ? cand : -1);
-            }
+            for (int rb = KB + 1; rb < NR; ++rb) key_out = max(key_out, __double2hiint(c_abs2(m[KB][rb])));
             // every lane inverts its own in-block candidate while the search runs; the winner's is used
             const cplx myinv = c_inv_fast(m[KB][KB]);
             key_blk = row16_max_i32(key_blk);
-            const int p = 63 - (key_blk & 63);
-            // pivot value and inverse: lane (p & 15) of this 16-lane group, as wave-uniform scalars
-            const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | (p & 15));
+            const int pl = 15 - (key_blk & 15);
+            // pivot value and inverse: lane pl of this 16-lane group, as wave-uniform scalars
+            const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | pl);
             const cplx piv = c_make(readlane_f64(m[KB][KB].x, src), readlane_f64(m[KB][KB].y, src));
             const cplx inv = c_make(readlane_f64(myinv.x, src), readlane_f64(myinv.y, src));
+            const bool keep = live && tj != pl;
+            const cplx r0 = c_mul(m[KB][KB], inv);
+            rowbuf[par][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
 #pragma unroll
-            for (int rb = KB; rb < NR; ++rb) {
-                const int j = 16 * rb + tj;
-                const bool live = j < D && !((done >> j) & 1ull) && j != p;
-                rowbuf[par][j] = live ? c_mul(m[KB][rb], inv) : c_make(0.0, 0.0);
-            }
-            // |pivot|^2 more than 2^8 below some live |a_kj|^2 outside the block: the pivoted fallback redoes it
-            const bool too_small = (key_out & ~63) - (key_blk & ~63) > (8 << 20);
-            const unsigned long long any_small = __ballot(too_small);
+            for (int rb = KB + 1; rb < NR; ++rb) rowbuf[par][16 * rb + tj] = c_mul(m[KB][rb], inv);
+            // |pivot|^2 more than 2^8 below some |a_kj|^2 outside the block: the pivoted fallback redoes it
+            const unsigned long long any_small = __ballot((key_out & ~15) - (key_blk & ~15) > (8 << 20));
             if (tj == 0) {
                 PivotRecord rec;
-                rec.re = piv.x; rec.im = piv.y; rec.col = p; rec.pad = 0;
+                rec.re = piv.x; rec.im = piv.y; rec.col = 16 * KB + pl; rec.pad = 0;
                 pivrec[par] = rec;
-                permseq[k] = p;
+                permseq[k] = 16 * KB + pl;
                 if (any_small) *weak = 1;
             }
         }
@@ -173,8 +169,9 @@ __device__ __forceinline__ bool eliminate_block(cplx (&m)[NR][NR], cplx &det, un
         STAMP(st, 2);
         if (rec.re == 0.0 && rec.im == 0.0) return false;
         if (tid < 64) det = c_mul(det, c_make(rec.re, rec.im));
-        done |= 1ull << rec.col;
-        eliminate<NR, KB>(m, r, kt, ti, rec.col & 15, st);
+        const int pl = rec.col & 15;
+        live = live && tj != pl;
+        eliminate<NR, KB>(m, r, kt, ti, pl, st);
         STAMP(st, 4);
     }
     return true;
@@ -292,7 +289,6 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
 
         // ---------------- phase C: determinant in registers ----------------
         cplx det = c_make(1.0, 0.0);
-        unsigned long long done = 0ull;
         bool singular = false;
         Stamps st;
 #ifdef SC_STAMPS
@@ -300,10 +296,10 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         st.last = 0; st.base = 0;
 #endif
         if (!(A.mode & 0x100)) {                 // 0x100: debug, skip the elimination (SC_DEBUG_SKIP_LU)
-            bool ok = eliminate_block<NR, 0>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
-            if (NR > 1 && ok) ok = eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
-            if (NR > 2 && ok) ok = eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
-            if (NR > 3 && ok) ok = eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, done, D, rowbuf, pivrec, permseq, &weak, st);
+            bool ok = eliminate_block<NR, 0>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
+            if (NR > 1 && ok) ok = eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
+            if (NR > 2 && ok) ok = eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
+            if (NR > 3 && ok) ok = eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
             singular = !ok;
         }
 #ifdef SC_STAMPS
