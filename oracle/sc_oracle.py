@@ -581,3 +581,97 @@ def run_loop(propagator, potential, dt, nt, energy0_es=0.0):
         kic[t] = propagator.ic_correlation(potential, energy0_es)
         propagator.step(potential, dt)
     return cauto, kic
+
+
+# --------------------------------------------------------------------------
+# sGDML force field: energy, gradient and analytic Hessian (gdml_predictor.py:96-250)
+# --------------------------------------------------------------------------
+
+class GDMLOracle(object):
+    """E, dE/dr, d2E/drdr of an sGDML model for batches (B, 3N); restatement of GDMLPredict.forward.
+
+    model keys used: sig, c, std, z, R_desc (Dd, M), R_d_desc_alpha (M, Dd), perms, tril_perms_lin
+    (gdml_predictor.py:57-85).  The descriptor is x_d = 1/|r_i - r_j| over the pairs i > j in
+    torch.tril_indices order.
+    """
+
+    def __init__(self, model):
+        sig, self.c, self.std = int(model['sig']), float(model['c']), float(model.get('std', 1))
+        self.q = np.sqrt(5) / sig
+        self.n_atoms = int(np.asarray(model['z']).shape[0])
+        desc = np.asarray(model['R_desc']).shape[0]
+        n_perms = np.asarray(model['perms']).shape[0]
+        perm = torch.tensor(np.asarray(model['tril_perms_lin'])).view(-1, n_perms).t()
+        expand = lambda xs: xs.repeat(1, n_perms)[:, perm].reshape(-1, desc)
+        self.xs_train = expand(torch.tensor(np.asarray(model['R_desc'], dtype=np.float64)).t())
+        self.Jx_alphas = expand(torch.tensor(np.asarray(model['R_d_desc_alpha'], dtype=np.float64)))
+        self.pair_i, self.pair_j = torch.tril_indices(self.n_atoms, self.n_atoms, offset=-1)
+
+    def forward(self, r):
+        N, q, A = self.n_atoms, self.q, self.Jx_alphas
+        B = r.shape[0]
+        k, l = self.pair_i, self.pair_j
+        Dd = k.shape[0]
+        pos = r.reshape(B, N, 3)
+        diff = pos[:, k, :] - pos[:, l, :]                       # (B, Dd, 3)
+        xs = 1.0 / diff.norm(dim=-1)                              # (B, Dd)
+        xd = xs[:, None, :] - self.xs_train                       # (B, M, Dd)
+        dist = xd.norm(dim=-1)                                    # (B, M)
+        XA = torch.einsum('bmd,md->bm', xd, A)
+        ef = 1.0 / 3.0 * q ** 4 * torch.exp(-q * dist)
+        f = ef * (1.0 + q * dist) / q ** 2
+        energy = torch.einsum('bm,bm->b', f, XA) * self.std + self.c
+        # Jacobian of the descriptor: row d has -x^3 diff on atom k and +x^3 diff on atom l
+        jac = torch.zeros(B, Dd, N, 3, dtype=r.dtype)
+        idx = torch.arange(Dd)
+        jd = -(xs ** 3)[:, :, None] * diff
+        jac[:, idx, k, :] = jd
+        jac[:, idx, l, :] -= jd
+        jac = jac.reshape(B, Dd, 3 * N)
+        gx = torch.einsum('bm,md->bd', f, A) - torch.einsum('bm,bmd->bd', ef * XA, xd)
+        grad = torch.einsum('bd,bdx->bx', gx, jac) * self.std
+        XJ = torch.einsum('bmd,bdx->bmx', xd, jac)
+        AJ = torch.einsum('md,bdx->bmx', A, jac)
+        JJ = torch.einsum('bdx,bdy->bxy', jac, jac)
+        hess = torch.einsum('bm,bmx,bmy->bxy', ef * XA * q / dist, XJ, XJ)
+        hess -= torch.einsum('bm,bxy->bxy', ef * XA, JJ)
+        hess -= torch.einsum('bm,bmx,bmy->bxy', ef, AJ, XJ)
+        hess -= torch.einsum('bm,bmx,bmy->bxy', ef, XJ, AJ)
+        # second derivatives of the descriptor: T_d = 3 g x^5 diff diff^T - g x^3 1 on the (k,k), (l,l) blocks, -T_d on (k,l), (l,k)
+        T = (3 * (gx * xs ** 5)[:, :, None, None] * diff[:, :, :, None] * diff[:, :, None, :]
+             - (gx * xs ** 3)[:, :, None, None] * torch.eye(3))
+        H4 = hess.reshape(B, N, 3, N, 3)
+        for d in range(Dd):
+            a, b = int(k[d]), int(l[d])
+            H4[:, a, :, a, :] += T[:, d]
+            H4[:, b, :, b, :] += T[:, d]
+            H4[:, a, :, b, :] -= T[:, d]
+            H4[:, b, :, a, :] -= T[:, d]
+        return energy, grad, hess * self.std
+
+
+class MolecularGDMLOracle(object):
+    """potentials.py:641-744 with arrays instead of an fchk object"""
+
+    def __init__(self, model, masses, nac0, origin=0.0):
+        self.gdml = GDMLOracle(model)
+        self._masses = torch.as_tensor(np.asarray(masses), dtype=torch.float64)
+        self.nac0 = torch.as_tensor(np.asarray(nac0), dtype=torch.float64)
+        self._dim = self._masses.shape[0]
+        self._origin = float(origin)
+
+    def dimensions(self):
+        return self._dim
+
+    def masses(self):
+        return self._masses
+
+    def harmonic_approximation(self, r):
+        v, g, h = self.gdml.forward(r.permute(1, 0))
+        return v - self._origin, g.permute(1, 0), h.permute(1, 2, 0)
+
+    def derivative_coupling_1st(self, r):
+        return self.nac0.unsqueeze(1).expand_as(r)
+
+    def derivative_coupling_2nd(self, r):
+        return torch.zeros_like(r)

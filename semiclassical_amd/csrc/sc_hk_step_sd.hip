@@ -285,6 +285,11 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                                         0.5 * (-SC_HBAR * sta * sib * mqp + (1.0 / SC_HBAR) * ista * isib * mpq))
                                : c_make(0.0, 0.0);
             }
+#ifdef SC_PHASEB_FENCE
+            // one row slot of loads in flight at a time (register budget at 4 waves/SIMD)
+            __asm__ volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 
         // ---------------- phase C: determinant in registers ----------------

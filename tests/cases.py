@@ -9,6 +9,7 @@ from oracle import sc_oracle as orc
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 HK_CASES = ["hk_1d", "hk_as5_chi000", "hk_as5_chi002", "hk_as60", "hk_as60_dt20", "hk_methylium"]
+GDML_CASES = ["hk_coumarin_gdml"]
 WM_CASES = ["wm_1d", "wm_as5_chi002", "wm_methylium"]
 
 
@@ -29,6 +30,8 @@ def oracle_potential(g):
     if kind == "harmonic":
         return orc.MolecularHarmonicOracle(g["pos0"], g["energy0"], g["grad0"], g["hess0"], g["masses"],
                                            g["nac0"], origin=float(g["origin"]))
+    if kind == "gdml":
+        return orc.MolecularGDMLOracle(load("gdml_coumarin_model"), g["masses"], g["nac0"], origin=float(g["origin"]))
     raise ValueError(kind)
 
 

@@ -11,7 +11,7 @@ torch.set_default_dtype(torch.float64)
 TOL = 1e-11
 
 
-@pytest.mark.parametrize("name", cases.HK_CASES + cases.WM_CASES)
+@pytest.mark.parametrize("name", cases.HK_CASES + cases.WM_CASES + cases.GDML_CASES)
 def test_oracle_matches_reference(name):
     g = cases.load(name)
     pot = cases.oracle_potential(g)
@@ -80,3 +80,14 @@ def test_sym_sqrtm():
     s, i = orc.sym_sqrtm(A)
     assert np.allclose(s.numpy(), sla.sqrtm(A.numpy()))
     assert np.allclose(i.numpy(), sla.inv(sla.sqrtm(A.numpy())))
+
+
+def test_gdml_oracle_matches_reference_predictor():
+    """E, grad, Hessian of the sGDML restatement vs GDMLPredict.forward of the reference (golden)"""
+    g = cases.load("gdml_coumarin_eval")
+    gd = orc.GDMLOracle(cases.load("gdml_coumarin_model"))
+    e, grad, hess = gd.forward(torch.from_numpy(g["r"]))
+    assert cases.rel_err(e.numpy(), g["energy"]) < 1e-14
+    assert cases.rel_err(grad.numpy(), g["grad"]) < 1e-12
+    assert cases.rel_err(hess.numpy(), g["hess"]) < 1e-12
+    assert torch.allclose(hess, hess.transpose(1, 2), atol=1e-10)        # reference tests/test_gdml_predictor.py:90-122
