@@ -120,6 +120,26 @@ typedef struct sc_wm_consts {
     double *detA, *detM, *sgnA, *sgnM;
 } sc_wm_consts;
 
+/* sGDML force field, reference semiclassical/gdml_predictor.py:57-85 (constructor) and :96-250 (forward).
+ *   xs_train, jx_alphas [n_train][n_desc]: permutation-expanded training descriptors and Jacobian-contracted
+ *   coefficients; pair_k/pair_l [n_desc]: atoms (k > l) of descriptor d in torch.tril_indices order;
+ *   q = sqrt(5)/sigma; energies are returned relative to `origin` (potentials.py:699). */
+typedef struct sc_gdml_model {
+    int32_t n_atoms, n_desc, n_train, _pad;
+    const double *xs_train, *jx_alphas;
+    const int32_t *pair_k, *pair_l;
+    double q, c, std, origin;
+    const double *inv_mass;     /* [3 n_atoms] */
+} sc_gdml_model;
+
+/* per-trajectory scratch of the unfused RK4 step for dense, position-dependent Hessians */
+typedef struct sc_dense_scratch {
+    double *hess;   /* [n][4][D][D]  stage Hessians */
+    double *kprev;  /* [n][2D]       slopes of (q, p) of the previous stage */
+    double *ksum;   /* [n][2D]       weighted slope sums k1 + 2 k2 + 2 k3 (+ k4) */
+    double *ssum;   /* [n]           weighted sums of T - V */
+} sc_dense_scratch;
+
 int         sc_version(void);
 const char *sc_last_error(void);
 
@@ -175,6 +195,24 @@ int sc_wm_grid(int64_t n, int32_t dim);
 int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi, const double *probi,
                     double mc_norm, int32_t track, int32_t has_nac, double *cq_out, double *kq_out,
                     double *partials, void *stream);
+
+/* E - origin [n], dE/dr [n][3N], d2E/drdr [n][3N][3N] of the sGDML model at the geometries r [n][3N].
+ * Replaces GDMLPredict.forward / MolecularGDMLPotential.harmonic_approximation (gdml_predictor.py:96-250). */
+int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, double *energy, double *grad, double *hess,
+                 void *stream);
+
+/* One RK4 stage (stage = 0..3) of (q, p, S) on the sGDML surface: stage point from the previous slope, potential
+ * evaluation, slopes, stage Hessian -> sc->hess; stage 3 also writes the new (q, p, S) and the per-workgroup sums of
+ * T+V (energy_partials[sc_dense_grid()]).  With sc_dense_mono_step it replaces _rk4_step / EquationsOfMotion.f
+ * (propagators.py:86-119, 313-383) for potentials whose Hessian is dense and position dependent. */
+int sc_dense_grid(int64_t n);
+int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const sc_dense_scratch *sc, double dt, int32_t stage,
+                  double *energy_partials, void *stream);
+
+/* RK4 of the four monodromy blocks with the four stage Hessians hess[n][4][D][D], then the HK prefactor (diagonal or
+ * dense/rank-deficient width matrices) and its branch tracking; D <= 64.  mode as in sc_hk_step. */
+int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
+                       double dt, int32_t mode, void *stream);
 
 /* Energy-conservation guard on the device, reference propagators.py:385-398 (check_energy_conservation).
  * elog[4] = { <T+V>(t-dt), <T+V>(t), largest |change| seen so far, number of steps logged }.

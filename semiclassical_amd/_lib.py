@@ -53,6 +53,17 @@ class sc_wm_consts(C.Structure):
                 ("detA", c_double_p), ("detM", c_double_p), ("sgnA", c_double_p), ("sgnM", c_double_p)]
 
 
+class sc_gdml_model(C.Structure):
+    _fields_ = [("n_atoms", C.c_int32), ("n_desc", C.c_int32), ("n_train", C.c_int32), ("_pad", C.c_int32),
+                ("xs_train", c_double_p), ("jx_alphas", c_double_p), ("pair_k", C.c_void_p), ("pair_l", C.c_void_p),
+                ("q", C.c_double), ("c", C.c_double), ("std", C.c_double), ("origin", C.c_double),
+                ("inv_mass", c_double_p)]
+
+
+class sc_dense_scratch(C.Structure):
+    _fields_ = [("hess", c_double_p), ("kprev", c_double_p), ("ksum", c_double_p), ("ssum", c_double_p)]
+
+
 SC_POT_MORSE, SC_POT_HARMONIC_SEP, SC_POT_EPS_MORSE, SC_POT_HARMONIC_DENSE = 1, 2, 3, 4
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
@@ -74,6 +85,13 @@ SIGNATURES = {
     "sc_wm_grid": (C.c_int, [C.c_int64, C.c_int32]),
     "sc_wm_correlate": (C.c_int, [P(sc_state), P(sc_wm_consts), c_double_p, c_double_p, C.c_double, C.c_int32,
                                   C.c_int32, c_double_p, c_double_p, c_double_p, C.c_void_p]),
+    "sc_gdml_eval": (C.c_int, [P(sc_gdml_model), c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p,
+                               C.c_void_p]),
+    "sc_dense_grid": (C.c_int, [C.c_int64]),
+    "sc_gdml_stage": (C.c_int, [P(sc_gdml_model), P(sc_state), P(sc_dense_scratch), C.c_double, C.c_int32,
+                                c_double_p, C.c_void_p]),
+    "sc_dense_mono_step": (C.c_int, [P(sc_state), P(sc_hk_consts), c_double_p, c_double_p, C.c_double, C.c_int32,
+                                     C.c_void_p]),
     "sc_reduce_slot": (C.c_int, [c_double_p, C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p,
                                  C.c_void_p]),
 }

@@ -1,0 +1,467 @@
+// sGDML force field (energy, gradient, analytic Hessian) and the RK4 step for potentials with a dense,
+// position-dependent Hessian.
+//
+// Reference semantics reproduced (paths relative to the reference repository):
+//   GDMLPredict.forward                     semiclassical/gdml_predictor.py:96-250
+//   MolecularGDMLPotential                  semiclassical/potentials.py:641-744
+//   RK4 + equations of motion               semiclassical/propagators.py:86-119, 313-383
+//   HK prefactor + branch tracking          semiclassical/propagators.py:951-1052
+//
+// Structure of one time step (the Hessian depends on the stage position, so the four stages cannot be fused):
+//   sc_gdml_stage(s), s = 0..3   one workgroup per trajectory: stage point (q_s, p_s) from the previous slope,
+//                                V, grad V, hess V of the sGDML model there; slopes of (q, p, S); hess V -> scratch;
+//                                after stage 3 the new (q, p, S) and the <T+V> partial sums
+//   sc_dense_mono_step           one workgroup per trajectory: RK4 of the four monodromy blocks with the four stage
+//                                Hessians (D x D times D x 2D products, Q stage matrix and Hessian staged in LDS,
+//                                the thread's elements and RK4 accumulators in registers), prefactor matrix,
+//                                pivoted LU determinant, branch tracking
+//
+// sGDML evaluation per geometry (Dd = N(N-1)/2 inverse distances x_d, M training points, q = sqrt(5)/sigma):
+//   xd_m = x - x_m,  d_m = |xd_m|,  XA_m = xd_m . A_m,  e_m = q^4/3 exp(-q d_m),  f_m = e_m (1 + q d_m)/q^2
+//   E = std sum_m f_m XA_m + c
+//   g_x = sum_m f_m A_m - e_m XA_m xd_m                        grad = std J^T g_x
+//   hess = std [ sum_m w_m XJ_m XJ_m^T - e_m (AJ_m XJ_m^T + XJ_m AJ_m^T) - (sum_m e_m XA_m) J^T J + sum_d g_x[d] d2x_d ]
+//   with w_m = e_m XA_m q / d_m, XJ_m = J^T xd_m, AJ_m = J^T A_m.  The Jacobian row of pair d = (k, l) is
+//   jd = -x_d^3 (r_k - r_l) on atom k and -jd on atom l, so J^T v is a gather over the N-1 partners of an atom,
+//   J^T J and the second-derivative term are 3x3 blocks per atom pair.  Everything is organised by atom-pair blocks.
+#include "sc_common.h"
+#include "sc_prefactor.h"
+
+namespace {
+
+__device__ __forceinline__ int pair_index(int a, int b) {      // a != b; torch.tril_indices order (i > j)
+    return a > b ? a * (a - 1) / 2 + b : b * (b - 1) / 2 + a;
+}
+
+struct GdmlLds {
+    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *XJ, *AJ, *red;
+};
+
+#define GDML_CHUNK 32
+
+__device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt) {
+    GdmlLds L;
+    double *f = base;
+    L.red = f;  f += 32;
+    L.pos = f;  f += 3 * N;
+    L.x = f;    f += Dd;
+    L.jd = f;   f += 3 * Dd;
+    L.gx = f;   f += Dd;
+    L.fm = f;   f += Mt;
+    L.em = f;   f += Mt;
+    L.wm = f;   f += Mt;
+    L.ea = f;   f += Mt;
+    L.grad = f; f += 3 * N;
+    L.XJ = f;   f += GDML_CHUNK * 3 * N;
+    L.AJ = f;   f += GDML_CHUNK * 3 * N;
+    return L;
+}
+
+size_t gdml_lds_doubles(int N, int Dd, int Mt) {
+    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + 2 * (size_t)GDML_CHUNK * 3 * N;
+}
+
+// V (without origin), grad[3N] (LDS, L.grad) and hess[3N][3N] (global, row-major) at the geometry in L.pos.
+// Every thread returns the energy.
+__device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess) {
+    const int N = G.n_atoms, Dd = G.n_desc, Mt = G.n_train, X = 3 * N;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+    const double q = G.q;
+    // ---- descriptor and Jacobian rows
+    for (int d = tid; d < Dd; d += nth) {
+        const int k = G.pair_k[d], l = G.pair_l[d];
+        const double dx = L.pos[3 * k] - L.pos[3 * l], dy = L.pos[3 * k + 1] - L.pos[3 * l + 1],
+                     dz = L.pos[3 * k + 2] - L.pos[3 * l + 2];
+        const double x = 1.0 / sqrt(dx * dx + dy * dy + dz * dz), x3 = x * x * x;
+        L.x[d] = x;
+        L.jd[3 * d] = -x3 * dx; L.jd[3 * d + 1] = -x3 * dy; L.jd[3 * d + 2] = -x3 * dz;
+    }
+    __syncthreads();
+    // ---- per-training-point scalars (one wave per m, lanes over the descriptor)
+    double esum = 0.0, ssum = 0.0;
+    for (int m = wave; m < Mt; m += nw) {
+        const double *xs = G.xs_train + (size_t)m * Dd, *A = G.jx_alphas + (size_t)m * Dd;
+        double s2 = 0.0, sa = 0.0;
+        for (int d = lane; d < Dd; d += 64) {
+            const double xd = L.x[d] - xs[d];
+            s2 = fma(xd, xd, s2);
+            sa = fma(xd, A[d], sa);
+        }
+        s2 = wave_sum(s2); sa = wave_sum(sa);
+        if (lane == 0) {
+            const double dist = sqrt(s2), e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
+            const double f = e * (1.0 + q * dist) / (q * q);
+            L.fm[m] = f; L.em[m] = e; L.wm[m] = e * sa * q / dist; L.ea[m] = e * sa;
+            esum += f * sa; ssum += e * sa;
+        }
+    }
+    double red2[2] = {esum, ssum};
+    block_sum<2>(red2, L.red);
+    const double energy = red2[0] * G.std + G.c, S = red2[1];
+    __syncthreads();
+    // ---- gradient in descriptor space, then Cartesian gradient
+    for (int d = tid; d < Dd; d += nth) {
+        double g = 0.0;
+        const double xv = L.x[d];
+        for (int m = 0; m < Mt; ++m)
+            g += L.fm[m] * G.jx_alphas[(size_t)m * Dd + d] - L.ea[m] * (xv - G.xs_train[(size_t)m * Dd + d]);
+        L.gx[d] = g;
+    }
+    __syncthreads();
+    for (int xi = tid; xi < X; xi += nth) {
+        const int a = xi / 3, u = xi - 3 * a;
+        double g = 0.0;
+        for (int b = 0; b < N; ++b) {
+            if (b == a) continue;
+            const int d = pair_index(a, b);
+            const double j = L.jd[3 * d + u] * L.gx[d];
+            g += (a > b) ? j : -j;
+        }
+        L.grad[xi] = g * G.std;
+    }
+    // ---- Hessian by atom-pair blocks (a <= b); a thread may own several blocks
+    const int nblk = N * (N + 1) / 2;
+    for (int blk0 = 0; blk0 < nblk; blk0 += nth) {
+        const int blk = blk0 + tid;
+        int a = 0, b = 0;
+        const bool own = blk < nblk;
+        if (own) {   // blk = b (b+1)/2 + a with a <= b
+            b = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+            while (b * (b + 1) / 2 > blk) --b;
+            while ((b + 1) * (b + 2) / 2 <= blk) ++b;
+            a = blk - b * (b + 1) / 2;
+        }
+        double h[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int m0 = 0; m0 < Mt; m0 += GDML_CHUNK) {
+            const int mc = min(GDML_CHUNK, Mt - m0);
+            __syncthreads();
+            // XJ_m = J^T xd_m, AJ_m = J^T A_m for the chunk
+            for (int e = tid; e < mc * X; e += nth) {
+                const int mm = e / X, xi = e - mm * X, at = xi / 3, u = xi - 3 * at, m = m0 + mm;
+                const double *xs = G.xs_train + (size_t)m * Dd, *A = G.jx_alphas + (size_t)m * Dd;
+                double sx = 0.0, sa = 0.0;
+                for (int c = 0; c < N; ++c) {
+                    if (c == at) continue;
+                    const int d = pair_index(at, c);
+                    const double j = (at > c) ? L.jd[3 * d + u] : -L.jd[3 * d + u];
+                    sx = fma(j, L.x[d] - xs[d], sx);
+                    sa = fma(j, A[d], sa);
+                }
+                L.XJ[e] = sx; L.AJ[e] = sa;
+            }
+            __syncthreads();
+            if (own) {
+                for (int mm = 0; mm < mc; ++mm) {
+                    const double w = L.wm[m0 + mm], e = L.em[m0 + mm];
+                    const double *xj = L.XJ + mm * X, *aj = L.AJ + mm * X;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const double xa = xj[3 * a + u], aa = aj[3 * a + u];
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) {
+                            const double xb = xj[3 * b + v], ab = aj[3 * b + v];
+                            h[u][v] += w * xa * xb - e * (aa * xb + xa * ab);
+                        }
+                    }
+                }
+            }
+        }
+        if (own) {
+            // - S J^T J + second derivatives of the descriptor
+            if (a != b) {
+                const int d = pair_index(a, b);          // b > a: b is the "k" atom of the pair
+                const double x = L.x[d], g = L.gx[d];
+                const double jx = L.jd[3 * d], jy = L.jd[3 * d + 1], jz = L.jd[3 * d + 2];
+                const double jv[3] = {jx, jy, jz};
+                // diff = r_k - r_l = -jd / x^3
+                const double ix3 = -1.0 / (x * x * x);
+                const double df[3] = {jx * ix3, jy * ix3, jz * ix3};
+                const double x5 = x * x * x * x * x, x3 = x * x * x;
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
+                        h[u][v] += S * jv[u] * jv[v] - T;          // J^T J block is -jd jd^T
+                    }
+            } else {
+                for (int c = 0; c < N; ++c) {
+                    if (c == a) continue;
+                    const int d = pair_index(a, c);
+                    const double x = L.x[d], g = L.gx[d];
+                    const double jv[3] = {L.jd[3 * d], L.jd[3 * d + 1], L.jd[3 * d + 2]};
+                    const double ix3 = -1.0 / (x * x * x);
+                    const double df[3] = {jv[0] * ix3, jv[1] * ix3, jv[2] * ix3};
+                    const double x5 = x * x * x * x * x, x3 = x * x * x;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) {
+                            const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
+                            h[u][v] += -S * jv[u] * jv[v] + T;
+                        }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const double val = h[u][v] * G.std;
+                    hess[(size_t)(3 * a + u) * X + 3 * b + v] = val;
+                    hess[(size_t)(3 * b + v) * X + 3 * a + u] = val;
+                }
+        }
+    }
+    __syncthreads();
+    return energy;
+}
+
+// ------------------------------------------------------------------ function-level evaluation
+struct EvalArgs {
+    sc_gdml_model G;
+    const double *r;
+    int64_t n;
+    double *energy, *grad, *hess;
+};
+
+__global__ __launch_bounds__(256) void gdml_eval_kernel(EvalArgs A) {
+    extern __shared__ double smem[];
+    const int X = 3 * A.G.n_atoms;
+    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train);
+    for (int64_t tr = blockIdx.x; tr < A.n; tr += gridDim.x) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < X; i += blockDim.x) L.pos[i] = A.r[tr * X + i];
+        __syncthreads();
+        const double e = gdml_eval_device(A.G, L, A.hess + (size_t)tr * X * X);
+        for (int i = threadIdx.x; i < X; i += blockDim.x) A.grad[tr * X + i] = L.grad[i];
+        if (threadIdx.x == 0) A.energy[tr] = e - A.G.origin;
+    }
+}
+
+// ------------------------------------------------------------------ RK4 stage of (q, p, S)
+struct StageArgs {
+    sc_gdml_model G;
+    sc_state st;
+    sc_dense_scratch sc;
+    double dt;
+    int stage;
+    double *epart;
+};
+
+__global__ __launch_bounds__(256) void gdml_stage_kernel(StageArgs A) {
+    extern __shared__ double smem[];
+    const int D = A.st.dim, tid = threadIdx.x, nth = blockDim.x, s = A.stage;
+    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train);
+    const double dt = A.dt, c = (s == 0) ? 0.0 : (s == 3 ? dt : 0.5 * dt), w = (s == 0 || s == 3) ? 1.0 : 2.0;
+    const double h6 = dt / 6.0;
+    double esum = 0.0;
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        double *qp = A.st.qp + tr * 2 * D;
+        double *kprev = A.sc.kprev + tr * 2 * D, *ksum = A.sc.ksum + tr * 2 * D;
+        __syncthreads();
+        double ps[2] = {0.0, 0.0};   // up to 2 coordinates per thread (D <= 512)
+        for (int i = tid, j = 0; i < D; i += nth, ++j) {
+            const double kq = s ? kprev[i] : 0.0, kp = s ? kprev[D + i] : 0.0;
+            L.pos[i] = qp[i] + c * kq;
+            ps[j] = qp[D + i] + c * kp;
+        }
+        __syncthreads();
+        const double e = gdml_eval_device(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D) - A.G.origin;
+        double tk[1] = {0.0};
+        for (int i = tid, j = 0; i < D; i += nth, ++j) {
+            const double im = A.G.inv_mass[i], kq = ps[j] * im, kp = -L.grad[i];
+            tk[0] += 0.5 * ps[j] * ps[j] * im;
+            kprev[i] = kq; kprev[D + i] = kp;
+            const double sq = (s ? ksum[i] : 0.0) + w * kq, sp = (s ? ksum[D + i] : 0.0) + w * kp;
+            if (s < 3) { ksum[i] = sq; ksum[D + i] = sp; }
+            else { qp[i] += h6 * sq; qp[D + i] += h6 * sp; }
+        }
+        block_sum<1>(tk, L.red);
+        if (tid == 0) {
+            const double ds = tk[0] - e, acc = (s ? A.sc.ssum[tr] : 0.0) + w * ds;
+            if (s < 3) A.sc.ssum[tr] = acc;
+            else { A.st.act[tr] += h6 * acc; esum += tk[0] + e; }
+        }
+    }
+    if (tid == 0 && A.epart && s == 3) A.epart[blockIdx.x] = esum;
+}
+
+// ------------------------------------------------------------------ RK4 of the monodromy blocks with 4 dense Hessians
+struct MonoArgs {
+    sc_state st;
+    sc_hk_consts hk;
+    const double *inv_mass;
+    const double *hess;     // [n][4][D][D]
+    double dt;
+    int mode;               // 0: step + prefactor, 1: prefactor only + tracker initialisation
+};
+
+#define MONO_NS 32          // register slots per thread: rows a = grp + G s, s < MONO_NS  (D <= 64)
+
+__global__ __launch_bounds__(256, 1) void dense_mono_kernel(MonoArgs A) {
+    extern __shared__ double2 smem2[];
+    __shared__ int ipiv;
+    double *smem = (double *)smem2;
+    const int D = A.st.dim, DD = D * D, W = 2 * D, tid = threadIdx.x, nth = blockDim.x;
+    const int dp = A.hk.dprime;
+    const bool diag = A.hk.diag != 0, do_step = A.mode == 0;
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    // column-owner mapping: thread -> (column col of the D x 2D matrices, row group grp)
+    const int G = nth / W, col = tid % W, grp = tid / W;
+    const bool active = grp < G;
+    const int plane_q = col < D ? 0 : 1, plane_p = col < D ? 2 : 3, cc = col < D ? col : col - D;
+    // LDS: RK4 phase {Q (D x 2D), H (D x D)} ; prefactor phase {mat (dp x dp complex), X (D x dp complex)}
+    double *Q = smem, *Hs = smem + (size_t)D * W;
+    cplx *mat = (cplx *)smem, *X = mat + (size_t)dp * dp;
+
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        double *M = A.st.mono + tr * 4 * (int64_t)DD;
+        __syncthreads();
+        if (do_step) {
+            double mq[MONO_NS], mp[MONO_NS], aq[MONO_NS], ap[MONO_NS], ps[MONO_NS];
+#pragma unroll
+            for (int s = 0; s < MONO_NS; ++s) {
+                const int a = grp + G * s;
+                const bool ok = active && a < D;
+                mq[s] = ok ? M[plane_q * DD + a * D + cc] : 0.0;
+                mp[s] = ok ? M[plane_p * DD + a * D + cc] : 0.0;
+                ps[s] = mp[s]; aq[s] = 0.0; ap[s] = 0.0;
+                if (ok) Q[a * W + col] = mq[s];
+            }
+            for (int st = 0; st < 4; ++st) {
+                const double *Hg = A.hess + ((size_t)tr * 4 + st) * DD;
+                for (int e = tid; e < DD; e += nth) Hs[e] = Hg[e];
+                __syncthreads();
+                double kp[MONO_NS];
+#pragma unroll
+                for (int s = 0; s < MONO_NS; ++s) kp[s] = 0.0;
+                if (active) {
+                    for (int g = 0; g < D; ++g) {
+                        const double qv = Q[g * W + col];
+#pragma unroll
+                        for (int s = 0; s < MONO_NS; ++s) {
+                            const int a = grp + G * s;
+                            if (a < D) kp[s] = fma(-Hs[a * D + g], qv, kp[s]);
+                        }
+                    }
+                }
+                __syncthreads();
+                const double w = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
+#pragma unroll
+                for (int s = 0; s < MONO_NS; ++s) {
+                    const int a = grp + G * s;
+                    if (active && a < D) {
+                        const double kq = ps[s] * A.inv_mass[a];
+                        aq[s] += w * kq; ap[s] += w * kp[s];
+                        if (st < 3) { Q[a * W + col] = mq[s] + c * kq; ps[s] = mp[s] + c * kp[s]; }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < MONO_NS; ++s) {
+                const int a = grp + G * s;
+                if (active && a < D) {
+                    M[plane_q * DD + a * D + cc] = mq[s] + h6 * aq[s];
+                    M[plane_p * DD + a * D + cc] = mp[s] + h6 * ap[s];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- prefactor from the (new) monodromy blocks in global memory
+        if (diag) {
+            for (int e = tid; e < DD; e += nth) {
+                const int a = e / D, b = e - a * D;
+                const double sta = A.hk.st[a], sib = A.hk.si[b];
+                mat[e] = c_make(0.5 * (sta / sib * M[e] + sib / sta * M[3 * DD + e]),
+                                0.5 * (-SC_HBAR * sta * sib * M[DD + e] + M[2 * DD + e] / (SC_HBAR * sta * sib)));
+            }
+            __syncthreads();
+        } else {
+            general_prefactor_matrix(A.hk, M, M + DD, M + 2 * DD, M + 3 * DD, D, X, mat);
+        }
+        const cplx det = lds_lu_det(mat, dp, &ipiv);
+        if (tid == 0) {
+            cplx *c2 = (cplx *)A.st.c2;
+            if (do_step) {
+                const cplx prev = c2[tr];
+                if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
+            } else {
+                A.st.sgn[tr] = 1.0;
+            }
+            c2[tr] = det;
+        }
+    }
+}
+
+size_t mono_lds_bytes(int D, int dp, int diag) {
+    const size_t rk4 = ((size_t)D * 2 * D + (size_t)D * D) * 8;
+    const size_t pre = ((size_t)dp * dp + (diag ? 0 : (size_t)D * dp)) * 16;
+    return (rk4 > pre ? rk4 : pre) + 32;
+}
+
+int check_model(const sc_gdml_model *g, const char *who) {
+    if (!g || !g->xs_train || !g->jx_alphas || !g->pair_k || !g->pair_l)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null model field", who);
+    if (g->n_desc != g->n_atoms * (g->n_atoms - 1) / 2)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: descriptor size %d does not match %d atoms", who, g->n_desc, g->n_atoms);
+    if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8 > 160 * 1024)
+        return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d, M=%d) needs more than 160 KiB of LDS", who, g->n_atoms, g->n_train);
+    return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, double *energy, double *grad,
+                            double *hess, void *stream) {
+    int rc = check_model(g, "sc_gdml_eval");
+    if (rc) return rc;
+    if (!r || !energy || !grad || !hess) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_eval: null argument");
+    if (n <= 0) return SC_OK;
+    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8;
+    EvalArgs a{*g, r, n, energy, grad, hess};
+    if (hipFuncSetAttribute((const void *)gdml_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sc_check_launch("sc_gdml_eval (LDS attribute)");
+    const int grid = (int)(n < 1024 ? n : 1024);
+    hipLaunchKernelGGL(gdml_eval_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    return sc_check_launch("sc_gdml_eval");
+}
+
+extern "C" int sc_dense_grid(int64_t n) { return (int)(n < 512 ? (n > 0 ? n : 1) : 512); }
+
+extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const sc_dense_scratch *sc, double dt,
+                             int32_t stage, double *energy_partials, void *stream) {
+    int rc = check_model(g, "sc_gdml_stage");
+    if (rc) return rc;
+    if (!st || !sc || !sc->hess || !sc->kprev || !sc->ksum || !sc->ssum)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_stage: null argument");
+    if (st->dim != 3 * g->n_atoms) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_stage: dimension mismatch");
+    if (stage < 0 || stage > 3) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_stage: stage %d", stage);
+    if (st->dim > 512) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_stage: D=%d > 512", st->dim);
+    if (st->n <= 0) return SC_OK;
+    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8;
+    StageArgs a{*g, *st, *sc, dt, stage, energy_partials};
+    if (hipFuncSetAttribute((const void *)gdml_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sc_check_launch("sc_gdml_stage (LDS attribute)");
+    hipLaunchKernelGGL(gdml_stage_kernel, dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a);
+    return sc_check_launch("sc_gdml_stage");
+}
+
+extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
+                                  double dt, int32_t mode, void *stream) {
+    if (!st || !hk || (mode == 0 && (!inv_mass || !hess)))
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: null argument");
+    const int D = st->dim;
+    if (D > 64 || 2 * D > 256) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d > 64", D);
+    if (hk->dim != D || hk->dprime < 1 || hk->dprime > D) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: bad prefactor constants");
+    const int G = 256 / (2 * D);
+    if ((D + G - 1) / G > MONO_NS) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d needs more register slots", D);
+    if (st->n <= 0) return SC_OK;
+    const size_t lds = mono_lds_bytes(D, hk->dprime, hk->diag);
+    if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: needs %zu B of LDS", lds);
+    MonoArgs a{*st, *hk, inv_mass, hess, dt, mode};
+    if (hipFuncSetAttribute((const void *)dense_mono_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sc_check_launch("sc_dense_mono_step (LDS attribute)");
+    hipLaunchKernelGGL(dense_mono_kernel, dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a);
+    return sc_check_launch("sc_dense_mono_step");
+}

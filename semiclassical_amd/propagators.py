@@ -24,7 +24,8 @@ import numpy as np
 import torch
 
 from . import _lib, hostmath
-from ._lib import lib, check, ptr, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts
+from ._lib import (lib, check, ptr, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts,
+                   sc_dense_scratch)
 from .units import hbar
 
 __all__ = ['HermanKlukPropagator', 'WaltonManolopoulosPropagator']
@@ -127,6 +128,7 @@ class HermanKlukPropagator(object):
         self._nsteps = 0
         self._corr_step, self._corr_has_nac = -1, False
         self._nac, self._nac_key = None, None
+        self._dense = None
 
         self._prepare()
         self.t = 0.0
@@ -179,21 +181,44 @@ class HermanKlukPropagator(object):
         self.t += float(dt)
 
     def _launch_step(self, potential, dt):
-        desc = self._potential_descriptor(potential)
         s = self._stream()
-        if getattr(self, "profile_step_kernel", False):
-            # HIP events on the launch stream, bracketing only the step kernel (bench.py roofline)
+        timed = getattr(self, "profile_step_kernel", False)
+        if timed:
+            # HIP events on the launch stream, bracketing only the step kernel(s) (bench.py roofline)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        if hasattr(potential, "_gdml_model"):
+            nblocks = self._launch_dense_step(potential, dt, s)
+        else:
+            desc = self._potential_descriptor(potential)
             check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
+            nblocks = self._gstep
+        if timed:
             e1.record()
             self.__dict__.setdefault("_step_events", []).append((e0, e1))
-        else:
-            check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
-        check(lib.sc_energy_guard(ptr(self._epart), self._gstep, float(self.ntraj), ptr(self._elog), s))
+        check(lib.sc_energy_guard(ptr(self._epart), nblocks, float(self.ntraj), ptr(self._elog), s))
         self._nsteps += 1
         self._remember_nac(potential)
         self._after_prefactor(track=1)
+
+    def _launch_dense_step(self, potential, dt, s):
+        """unfused RK4 step for a dense, position-dependent Hessian: four stage kernels + the monodromy kernel"""
+        n, d = self.ntraj, self.dim
+        if getattr(self, "_dense", None) is None:
+            dev = self.device
+            bufs = [torch.empty((n, 4, d, d), dtype=F64, device=dev), torch.zeros((n, 2 * d), dtype=F64, device=dev),
+                    torch.zeros((n, 2 * d), dtype=F64, device=dev), torch.zeros(n, dtype=F64, device=dev)]
+            self._dense_bufs = bufs
+            self._dense = sc_dense_scratch(hess=ptr(bufs[0]), kprev=ptr(bufs[1]), ksum=ptr(bufs[2]), ssum=ptr(bufs[3]))
+            self._gdense = lib.sc_dense_grid(n)
+            if self._gdense > self._epart.numel():
+                self._epart = torch.zeros(self._gdense, dtype=F64, device=dev)
+        with torch.cuda.device(self.device):
+            model = potential._gdml_model(self.device)
+        for stage in range(4):
+            check(lib.sc_gdml_stage(model, self._state, self._dense, dt, stage, ptr(self._epart), s))
+        check(lib.sc_dense_mono_step(self._state, self._hk, model.inv_mass, ptr(self._dense_bufs[0]), dt, 0, s))
+        return self._gdense
 
     def _after_prefactor(self, track):
         """hook for propagators whose prefactor needs more than the HK determinant (WM)"""

@@ -14,6 +14,23 @@ def engine_potential(g):
     if kind == "harmonic":
         return P.MolecularHarmonicPotential.from_arrays(g["pos0"], g["energy0"], g["grad0"], g["hess0"],
                                                         g["masses"], g["nac0"], origin=float(g["origin"]))
+    if kind == "gdml":
+        from semiclassical_amd.gdml import MolecularGDMLPotential
+
+        class _Fchk(object):
+            def nonadiabatic_coupling(self_):
+                return g["nac0"]
+
+            def masses(self_):
+                return g["masses"]
+
+            def atomic_numbers(self_):
+                return model["z"]
+        model = cases.load("gdml_coumarin_model")
+        pot = MolecularGDMLPotential(model, _Fchk())
+        pot._origin = float(g["origin"])
+        pot._invalidate_descriptor()
+        return pot
     raise ValueError(kind)
 
 

@@ -91,3 +91,17 @@ def test_gdml_oracle_matches_reference_predictor():
     assert cases.rel_err(grad.numpy(), g["grad"]) < 1e-12
     assert cases.rel_err(hess.numpy(), g["hess"]) < 1e-12
     assert torch.allclose(hess, hess.transpose(1, 2), atol=1e-10)        # reference tests/test_gdml_predictor.py:90-122
+
+
+def test_gdml_sum_conditioning():
+    """why GPU-vs-reference agreement on sGDML forces is ~1e-8, not 1e-13: the reference's own formula changes by
+    that much when the training points are summed in a different order (terms of 2e8 cancel to 6e1)"""
+    g = cases.load("gdml_coumarin_eval")
+    gd = orc.GDMLOracle(cases.load("gdml_coumarin_model"))
+    r = torch.from_numpy(g["r"])
+    _, grad, hess = gd.forward(r)
+    perm = torch.randperm(gd.xs_train.shape[0], generator=torch.Generator().manual_seed(0))
+    gd.xs_train, gd.Jx_alphas = gd.xs_train[perm], gd.Jx_alphas[perm]
+    _, grad2, hess2 = gd.forward(r)
+    assert 1e-10 < cases.rel_err(grad2.numpy(), grad.numpy()) < 1e-6
+    assert cases.rel_err(hess2.numpy(), hess.numpy()) < 1e-6

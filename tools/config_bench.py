@@ -45,6 +45,10 @@ def run(name, label):
           f"({wall / steps * 1e3:.3f} ms/step)  |C(0)|={abs(c[0]):.4f}", flush=True)
 
 
+if os.environ.get("GDML_ONLY"):
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    run("hk_coumarin_gdml", "config 5* HK  coumarin sGDML (17 atoms, M=200)")
+    sys.exit(0)
 run("hk_as5_chi002", "config 1  HK  5-mode anharmonic AS")
 run("wm_as5_chi002", "          WM  5-mode anharmonic AS")
 run("hk_methylium", "          HK  methylium harmonic")
