@@ -29,6 +29,7 @@ struct WmArgs {
     double mc_norm;
     int track;          // 0: use the stored branch signs, 1: track against the previous determinants, 2: initialise
     int has_nac;
+    int stage_consts;   // copy the D x D constants into LDS once per workgroup (when they fit)
     double *cq_out, *kq_out, *partials;
 };
 
@@ -118,6 +119,22 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     cplx *cv = c;                c += 5 * D;        // u_dq, u_n1, w_dQ(c), w_n1(c), y
     cplx *hat = c;               c += 5 * dp;       // U^T of the five vectors
     cplx *rho = c;               c += 5 * dp;       // iM' of them
+    double *rowtmp = (double *)c;                    // per-row partial results of the scalar tail (3 x D)
+    double *cst = rowtmp + 3 * D;                    // optional LDS copies of the constants
+
+    // constants: global pointers, or LDS copies when the host found room for them
+    const double *cU = W.U, *cGt = W.Gt, *cG0 = W.G0, *ciGi0 = W.iGi0, *cS = W.S, *cCqq = W.Cqq;
+    const double *cq0 = W.q0, *cp0 = W.p0, *cn1 = W.n1, *csn1 = W.s_n1, *cwn1 = W.w_n1;
+    if (A.stage_consts) {
+        double *d = cst;
+        auto stage = [&](const double *&ptr, int count) {
+            if (ptr) { for (int i = tid; i < count; i += nth) d[i] = ptr[i]; ptr = d; }
+            d += count;
+        };
+        stage(cU, D * dp); stage(cGt, DD); stage(cG0, DD); stage(ciGi0, DD); stage(cS, DD); stage(cCqq, DD);
+        stage(cq0, D); stage(cp0, D); stage(cn1, D); stage(csn1, D); stage(cwn1, D);
+        __syncthreads();
+    }
 
     const cplx *Cst = (const cplx *)W.Cst, *Bq = (const cplx *)W.Bq;
     const double ihb = 1.0 / SC_HBAR;
@@ -132,20 +149,20 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             const int a = e / E, j = e - a * E, blk = j >= dp, jj = blk ? j - dp : j;
             const double *Mqx = M + (blk ? DD : 0) + a * D, *Mpx = M + (blk ? 3 * DD : 2 * DD) + a * D;
             double sq = 0.0, sp = 0.0;
-            for (int b = 0; b < D; ++b) { const double u = W.U[b * dp + jj]; sq = fma(Mqx[b], u, sq); sp = fma(Mpx[b], u, sp); }
+            for (int b = 0; b < D; ++b) { const double u = cU[b * dp + jj]; sq = fma(Mqx[b], u, sq); sp = fma(Mpx[b], u, sp); }
             Mq[e] = sq; Mp[e] = sp;
         }
         for (int a = tid; a < D; a += nth) {
-            vec[a] = W.q0[a] - zi[a];                 // dq
-            vec[D + a] = W.q0[a] - qp[a];             // dQ
-            vec[2 * D + a] = W.p0[a] - zi[D + a];     // dp = p0 - p_initial
+            vec[a] = cq0[a] - zi[a];                 // dq
+            vec[D + a] = cq0[a] - qp[a];             // dQ
+            vec[2 * D + a] = cp0[a] - zi[D + a];     // dp = p0 - p_initial
         }
         __syncthreads();
         // Tq = Gamma_t Mq' ; G = Mp'^T Mq' ; g = iGi0 dp ; s_dq = S dq ; w_dQ = G0 dQ
         for (int e = tid; e < D * E; e += nth) {
             const int a = e / E, j = e - a * E;
             double s = 0.0;
-            for (int b = 0; b < D; ++b) s = fma(W.Gt[a * D + b], Mq[b * E + j], s);
+            for (int b = 0; b < D; ++b) s = fma(cGt[a * D + b], Mq[b * E + j], s);
             Tq[e] = s;
         }
         for (int e = tid; e < E * E; e += nth) {
@@ -157,9 +174,9 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
         for (int a = tid; a < D; a += nth) {
             double g = 0.0, s = 0.0, w = 0.0;
             for (int b = 0; b < D; ++b) {
-                g = fma(W.iGi0[a * D + b], vec[2 * D + b], g);
-                s = fma(W.S[a * D + b], vec[b], s);
-                w = fma(W.G0[a * D + b], vec[D + b], w);
+                g = fma(ciGi0[a * D + b], vec[2 * D + b], g);
+                s = fma(cS[a * D + b], vec[b], s);
+                w = fma(cG0[a * D + b], vec[D + b], w);
             }
             vec[3 * D + a] = g; vec[4 * D + a] = s; vec[5 * D + a] = w;
         }
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
                 s = c_fma(Wm[a * E + j], BQ[b * E + j], s);
                 t = c_fma(Wm[a * E + j], Bq[b * E + j], t);
             }
-            Gt[e] = c_make(W.Gt[e] - s.x, -s.y);
+            Gt[e] = c_make(cGt[e] - s.x, -s.y);
             Gti[e] = t;
         }
         __syncthreads();
@@ -201,21 +218,21 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
         for (int e = tid; e < DD; e += nth) {
             const int a = e / D, b = e - a * D;
             cplx s = c_make(0, 0);
-            for (int k = 0; k < D; ++k) { const double x = W.iGi0[k * D + b]; s.x = fma(Gti[a * D + k].x, x, s.x); s.y = fma(Gti[a * D + k].y, x, s.y); }
+            for (int k = 0; k < D; ++k) { const double x = ciGi0[k * D + b]; s.x = fma(Gti[a * D + k].x, x, s.x); s.y = fma(Gti[a * D + k].y, x, s.y); }
             V[e] = s;
         }
         for (int a = tid; a < D; a += nth) {
-            cplx y = c_make(qp[D + a] - W.p0[a], 0.0), u1 = c_make(0, 0), u2 = c_make(0, 0);
+            cplx y = c_make(qp[D + a] - cp0[a], 0.0), u1 = c_make(0, 0), u2 = c_make(0, 0);
             for (int b = 0; b < D; ++b) {
                 const cplx gt = Gti[a * D + b];
-                const double g = vec[3 * D + b], s1 = vec[4 * D + b], s2 = A.has_nac ? W.s_n1[b] : 0.0;
+                const double g = vec[3 * D + b], s1 = vec[4 * D + b], s2 = A.has_nac ? csn1[b] : 0.0;
                 y.x = fma(gt.x, g, y.x); y.y = fma(gt.y, g, y.y);
                 u1.x = fma(gt.x, s1, u1.x); u1.y = fma(gt.y, s1, u1.y);
                 u2.x = fma(gt.x, s2, u2.x); u2.y = fma(gt.y, s2, u2.y);
             }
             cv[a] = u1; cv[D + a] = u2;
             cv[2 * D + a] = c_make(vec[5 * D + a], 0.0);
-            cv[3 * D + a] = c_make(A.has_nac ? W.w_n1[a] : 0.0, 0.0);
+            cv[3 * D + a] = c_make(A.has_nac ? cwn1[a] : 0.0, 0.0);
             cv[4 * D + a] = y;
         }
         __syncthreads();
@@ -234,11 +251,11 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             for (int a = 0; a < D; ++a) {
                 cplx row = c_make(0, 0);
                 for (int b = 0; b < D; ++b) {
-                    const double u = W.U[b * dp + j];
-                    row.x = fma(W.G0[a * D + b] + Gt[a * D + b].x, u, row.x);
+                    const double u = cU[b * dp + j];
+                    row.x = fma(cG0[a * D + b] + Gt[a * D + b].x, u, row.x);
                     row.y = fma(Gt[a * D + b].y, u, row.y);
                 }
-                const double ui = W.U[a * dp + i];
+                const double ui = cU[a * dp + i];
                 s.x = fma(ui, row.x, s.x); s.y = fma(ui, row.y, s.y);
             }
             augM[i * 2 * dp + j] = c_scale(s, W.inv_two_pi);
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
         for (int e = tid; e < 5 * dp; e += nth) {
             const int v = e / dp, i = e - v * dp;
             cplx s = c_make(0, 0);
-            for (int a = 0; a < D; ++a) { const double u = W.U[a * dp + i]; s.x = fma(u, cv[v * D + a].x, s.x); s.y = fma(u, cv[v * D + a].y, s.y); }
+            for (int a = 0; a < D; ++a) { const double u = cU[a * dp + i]; s.x = fma(u, cv[v * D + a].x, s.x); s.y = fma(u, cv[v * D + a].y, s.y); }
             hat[e] = s;
         }
         __syncthreads();
@@ -261,6 +278,18 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
         }
         __syncthreads();
 
+        // row sums of the D x D constant forms, one row per thread
+        for (int a = tid; a < D; a += nth) {
+            double cdq = 0.0, cn1v = 0.0, g0g = 0.0;
+            for (int b = 0; b < D; ++b) {
+                cdq = fma(cCqq[a * D + b], vec[b], cdq);
+                if (A.has_nac) cn1v = fma(cCqq[a * D + b], cn1[b], cn1v);
+                g0g = fma(cG0[a * D + b], vec[3 * D + b], g0g);
+            }
+            rowtmp[a] = cdq; rowtmp[D + a] = cn1v; rowtmp[2 * D + a] = g0g;
+        }
+        __syncthreads();
+
         // ---- scalars: one thread per trajectory is enough (O(d'^2 + D) work) ----
         if (tid == 0) {
             auto form = [&](int a, int b) {                       // a^T iM b
@@ -271,19 +300,14 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             enum { UDQ = 0, UN1 = 1, WDQ = 2, WN1 = 3, Y = 4 };
             double dqCdq = 0, dqCn1 = 0, dQGdQ = 0, dQGn1 = 0, piq_dq = 0, piq_n1 = 0, p0_dQ = 0, eps = 0;
             for (int a = 0; a < D; ++a) {
-                double cdq = 0.0, cn1 = 0.0, g0g = 0.0;
-                for (int b = 0; b < D; ++b) {
-                    cdq = fma(W.Cqq[a * D + b], vec[b], cdq);
-                    if (A.has_nac) cn1 = fma(W.Cqq[a * D + b], W.n1[b], cn1);
-                    g0g = fma(W.G0[a * D + b], vec[3 * D + b], g0g);
-                }
-                const double piq = W.p0[a] - g0g;                                  // (72)
+                const double cdq = rowtmp[a], crow = rowtmp[D + a], g0g = rowtmp[2 * D + a];
+                const double piq = cp0[a] - g0g;                                  // (72)
                 dqCdq = fma(vec[a], cdq, dqCdq);
-                dqCn1 = fma(vec[a], cn1, dqCn1);
+                dqCn1 = fma(vec[a], crow, dqCn1);
                 dQGdQ = fma(vec[D + a], vec[5 * D + a], dQGdQ);
-                if (A.has_nac) { dQGn1 = fma(vec[D + a], W.w_n1[a], dQGn1); piq_n1 = fma(piq, W.n1[a], piq_n1); }
+                if (A.has_nac) { dQGn1 = fma(vec[D + a], cwn1[a], dQGn1); piq_n1 = fma(piq, cn1[a], piq_n1); }
                 piq_dq = fma(piq, vec[a], piq_dq);
-                p0_dQ = fma(W.p0[a], vec[D + a], p0_dQ);
+                p0_dQ = fma(cp0[a], vec[D + a], p0_dQ);
                 eps = fma(vec[2 * D + a], vec[3 * D + a], eps);
             }
             eps *= -0.5 * ihb * ihb;                                                // (74), b0 = 0
@@ -339,8 +363,10 @@ size_t wm_lds_bytes(int D, int dp) {
     const size_t E = 2 * (size_t)dp, DD = (size_t)D * D;
     size_t doubles = 3 * D * E + E * E + 8 * D + 1;
     size_t cplxs = E * 2 * E + 2 * D * E + 3 * DD + (size_t)dp * 2 * dp + (E > (size_t)D ? E : D) + 5 * D + 10 * dp;
-    return doubles * 8 + cplxs * 16 + 32;
+    return doubles * 8 + cplxs * 16 + 3 * (size_t)D * 8 + 32;
 }
+
+size_t wm_const_bytes(int D, int dp) { return ((size_t)D * dp + 5 * (size_t)D * D + 5 * (size_t)D) * 8; }
 
 }  // namespace
 
@@ -355,12 +381,14 @@ extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const
     if (!st || !wc || !zi || !probi || !partials) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: null argument");
     if (wc->dim != st->dim) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: dimension mismatch");
     if (st->n <= 0) return SC_OK;
-    const size_t lds = wm_lds_bytes(st->dim, wc->dprime);
+    size_t lds = wm_lds_bytes(st->dim, wc->dprime);
+    const int stage_consts = lds + wm_const_bytes(st->dim, wc->dprime) <= 64 * 1024;   // keep >= 2 workgroups per CU
+    if (stage_consts) lds += wm_const_bytes(st->dim, wc->dprime);
     if (lds > 160 * 1024)
         return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_correlate: D=%d d'=%d needs %zu B of LDS per trajectory (limit 160 KiB)",
                        st->dim, wc->dprime, lds);
     WmArgs a;
-    a.st = *st; a.wc = *wc; a.zi = zi; a.probi = probi; a.mc_norm = mc_norm; a.track = track; a.has_nac = has_nac;
+    a.st = *st; a.wc = *wc; a.zi = zi; a.probi = probi; a.mc_norm = mc_norm; a.track = track; a.has_nac = has_nac; a.stage_consts = stage_consts;
     a.cq_out = cq_out; a.kq_out = kq_out; a.partials = partials;
     if (hipFuncSetAttribute((const void *)wm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sc_check_launch("sc_wm_correlate (LDS attribute)");
