@@ -214,6 +214,14 @@ int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const sc_dense_scr
 int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
                        double dt, int32_t mode, void *stream);
 
+/* O(n^2) pairwise sum  sum_ij wb_i wk_j exp(rs_i + rs_j + X1_i.Y1_j + i (ib_i + ik_j + X2_i.Y2_j))  behind
+ * HermanKlukPropagator.norm() (propagators.py:734-782): X1/Y1 [n][K1], X2/Y2 [n][K2] real, rs/ib/ik [n] real,
+ * wb/wk [n] complex; partials[sc_pair_sum_tiles(n)][4] (re, im, 0, 0) for sc_reduce_slot. */
+int64_t sc_pair_sum_tiles(int64_t n);
+int sc_pair_sum(const double *X1, const double *Y1, int32_t K1, const double *X2, const double *Y2, int32_t K2,
+                const double *rs, const double *ib, const double *ik, const double *wb, const double *wk,
+                int64_t n, double *partials, void *stream);
+
 /* Energy-conservation guard on the device, reference propagators.py:385-398 (check_energy_conservation).
  * elog[4] = { <T+V>(t-dt), <T+V>(t), largest |change| seen so far, number of steps logged }.
  * The mean of this step is formed from energy_partials; the host raises the reference's RuntimeError when

@@ -1,0 +1,107 @@
+// Pairwise coherent-state sum  sum_ij wb_i wk_j exp( rs_i + rs_j + X1_i.Y1_j + i (ib_i + ik_j + X2_i.Y2_j) )
+// -- the O(n^2) kernel behind HermanKlukPropagator.norm() (reference semiclassical/propagators.py:734-782).
+//
+// With A = Gt (2Gt)^+ Gt, B = (2Gt)^+, C = Gt (2Gt)^+ the overlap <q_i,p_i,Gt|q_j,p_j,Gt> (propagators.py:230-237)
+// factorises into per-trajectory terms and five dot products per pair, which the host packs into two real
+// "GEMM" operands:  X1 = [q, p], Y1 = [A q, B p] (real part) and X2 = [q, C p, q], Y2 = [p, -q, -C p] (imaginary part).
+// One workgroup computes a 64 x 64 tile of pairs (4 x 4 pairs per thread, K staged through LDS in chunks of 16)
+// and writes one complex partial sum; sc_reduce_slot adds the partials in fixed order.
+#include "sc_common.h"
+
+namespace {
+
+struct PairArgs {
+    const double *X1, *Y1, *X2, *Y2;    // [n][K1], [n][K1], [n][K2], [n][K2]
+    int K1, K2;
+    const double *rs, *ib, *ik;         // [n] real
+    const double *wb, *wk;              // [n] complex
+    int64_t n;
+    double *partials;                   // [tiles][4], columns 2, 3 are zero
+};
+
+#define PT 64      // tile edge
+#define PK 16      // K chunk
+
+__global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs A) {
+    __shared__ double xs[PK][PT + 1], ys[PK][PT + 1];
+    __shared__ double red[32];
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int64_t tiles = (A.n + PT - 1) / PT;
+    const int64_t bi = blockIdx.x / tiles, bj = blockIdx.x % tiles;
+    const int64_t i0 = bi * PT, j0 = bj * PT;
+    double re[4][4], im[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { re[a][b] = 0.0; im[a][b] = 0.0; }
+    for (int part = 0; part < 2; ++part) {
+        const double *X = part ? A.X2 : A.X1, *Y = part ? A.Y2 : A.Y1;
+        const int K = part ? A.K2 : A.K1;
+        for (int k0 = 0; k0 < K; k0 += PK) {
+            __syncthreads();
+            for (int e = tid; e < PK * PT; e += 256) {
+                const int r = e / PK, k = e - r * PK;            // row r of the tile, column k of the chunk
+                const bool kin = k0 + k < K;
+                xs[k][r] = (kin && i0 + r < A.n) ? X[(i0 + r) * K + k0 + k] : 0.0;
+                ys[k][r] = (kin && j0 + r < A.n) ? Y[(j0 + r) * K + k0 + k] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PK; ++k) {
+                double xv[4], yv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { xv[a] = xs[k][4 * ti + a]; yv[a] = ys[k][4 * tj + a]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (part) im[a][b] = fma(xv[a], yv[b], im[a][b]);
+                        else re[a][b] = fma(xv[a], yv[b], re[a][b]);
+                    }
+            }
+        }
+    }
+    double acc[2] = {0.0, 0.0};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int64_t i = i0 + 4 * ti + a;
+        if (i >= A.n) continue;
+        const cplx wb = ((const cplx *)A.wb)[i];
+        const double rsi = A.rs[i], ibi = A.ib[i];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t j = j0 + 4 * tj + b;
+            if (j >= A.n) continue;
+            const cplx e = c_exp(c_make(rsi + A.rs[j] + re[a][b], ibi + A.ik[j] + im[a][b]));
+            const cplx t = c_mul(c_mul(wb, ((const cplx *)A.wk)[j]), e);
+            acc[0] += t.x; acc[1] += t.y;
+        }
+    }
+    block_sum<2>(acc, red);
+    if (tid == 0) {
+        A.partials[(size_t)blockIdx.x * 4 + 0] = acc[0];
+        A.partials[(size_t)blockIdx.x * 4 + 1] = acc[1];
+        A.partials[(size_t)blockIdx.x * 4 + 2] = 0.0;
+        A.partials[(size_t)blockIdx.x * 4 + 3] = 0.0;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t sc_pair_sum_tiles(int64_t n) {
+    const int64_t t = (n + PT - 1) / PT;
+    return t * t;
+}
+
+extern "C" int sc_pair_sum(const double *X1, const double *Y1, int32_t K1, const double *X2, const double *Y2, int32_t K2,
+                           const double *rs, const double *ib, const double *ik, const double *wb, const double *wk,
+                           int64_t n, double *partials, void *stream) {
+    if (!X1 || !Y1 || !X2 || !Y2 || !rs || !ib || !ik || !wb || !wk || !partials)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_pair_sum: null argument");
+    if (n <= 0) return SC_OK;
+    const int64_t tiles = sc_pair_sum_tiles(n);
+    if (tiles > 0x7fffffff) return sc_fail(SC_ERR_UNSUPPORTED, "sc_pair_sum: n=%lld needs more than 2^31 tiles", (long long)n);
+    PairArgs a{X1, Y1, X2, Y2, K1, K2, rs, ib, ik, wb, wk, n, partials};
+    hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    return sc_check_launch("sc_pair_sum");
+}

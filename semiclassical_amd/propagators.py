@@ -377,6 +377,43 @@ class HermanKlukPropagator(object):
     def semiclassical_prefactor(self):
         return self._sgn * torch.sqrt(self._c2)
 
+    def coefficients(self):
+        """expansion coefficients v_i of the wavefunction in the coherent states (reference propagators.py:657-686)"""
+        v = self.semiclassical_prefactor() * torch.exp(1j / hbar * self._act) * self._vi
+        return v / (self._mc_norm() * self.probi)
+
+    def norm(self):
+        """|psi| = sqrt(sum_ij v_i^* <q_i,p_i,Gamma_t|q_j,p_j,Gamma_t> v_j), O(n^2) (reference propagators.py:734-782).
+
+        The pair sum runs in ``sc_pair_sum``; the host only packs the operands: positions are centred (the overlaps
+        depend on differences) so that the per-trajectory and the cross terms of the exponent stay small.
+        """
+        dev, d, n = self.device, self.dim, self.ntraj
+        oc = hostmath.OverlapConstants(self._Gt, self._Gt)
+        A, B, Cm = (m.to(dev) for m in (oc.A, oc.B, oc.C))
+        q = self._qp[:, :d] - self._qp[:, :d].mean(0, keepdim=True)
+        p = self._qp[:, d:]
+        Aq, Bp, Cp = q @ A.T, p @ B.T / hbar ** 2, p @ Cm.T / hbar
+        # exponent_ij = rs_i + rs_j + X1_i.Y1_j + i (ib_i + ik_j + X2_i.Y2_j)   (propagators.py:232-237 expanded)
+        X1 = torch.cat((q, p), 1).contiguous()
+        Y1 = torch.cat((Aq, Bp), 1).contiguous()
+        X2 = torch.cat((q, Cp, q), 1).contiguous()
+        Y2 = torch.cat((p / hbar, -q, -Cp), 1).contiguous()
+        rs = (-0.5 * (q * Aq).sum(1) - 0.5 * (p * Bp).sum(1)).contiguous()
+        cc = (q * Cp).sum(1)
+        ib = cc.contiguous()
+        ik = (cc - (p * q).sum(1) / hbar).contiguous()
+        v = self.coefficients()
+        wb, wk = (oc.fac * v.conj()).contiguous(), v.contiguous()
+        tiles = lib.sc_pair_sum_tiles(n)
+        partials = torch.empty((tiles, 4), dtype=F64, device=dev)
+        slot = torch.zeros(8, dtype=F64, device=dev)
+        s = self._stream()
+        check(lib.sc_pair_sum(ptr(X1), ptr(Y1), 2 * d, ptr(X2), ptr(Y2), 3 * d, ptr(rs), ptr(ib), ptr(ik),
+                              ptr(wb), ptr(wk), n, ptr(partials), s))
+        check(lib.sc_reduce_slot(ptr(partials), int(tiles), None, 0, 1.0, ptr(slot), s))
+        return float(torch.sqrt(slot[0]).item())
+
     def _get_signs_of_sqrt(self, key):
         if key != "prefactorC":
             logger.error(f"Apparently the sign of the square root of the quantity '{key}' is not being tracked.")

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Golden values of HermanKlukPropagator.norm() / coefficients() from the REFERENCE.
+
+Build container only.  Uses the initial conditions (zi, probi) of existing golden cases, so the engine and the
+oracle can be started from identical states; stores the norm and the expansion coefficients after `nsteps` steps.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (torch aliases + reference import)
+from semiclassical.propagators import HermanKlukPropagator  # noqa: E402
+from semiclassical.potentials import MorsePotential, MolecularHarmonicPotential  # noqa: E402
+
+
+def run(name, potential, nsteps):
+    g = dict(np.load(os.path.join(HERE, name + ".npz")))
+    T = lambda x: torch.from_numpy(np.asarray(x)).clone()
+    torch.manual_seed(0)
+    prop = HermanKlukPropagator(T(g["Gamma_i"]), T(g["Gamma_t"]))
+    prop.initial_conditions(T(g["q0"]), T(g["p0"]), T(g["Gamma_0"]), ntraj=g["zi"].shape[1])
+    assert np.array_equal(prop.zi.numpy(), g["zi"])          # same seed => same initial conditions as the golden
+    out = {"norm_0": prop.norm(), "coeff_0": prop.coefficients().numpy()}
+    for _ in range(nsteps):
+        prop.step(potential, float(g["dt"]))
+    out.update({"nsteps": nsteps, f"norm_{nsteps}": prop.norm(), f"coeff_{nsteps}": prop.coefficients().numpy()})
+    print(name, out["norm_0"], out[f"norm_{nsteps}"])
+    return out
+
+
+def main():
+    g = dict(np.load(os.path.join(HERE, "hk_as5_chi002.npz")))
+    pot = MorsePotential(torch.from_numpy(g["omega"]), torch.from_numpy(g["chi"]).clone(), torch.from_numpy(g["nac"]))
+    res = {"as5_" + k: v for k, v in run("hk_as5_chi002", pot, 20).items()}
+    g = dict(np.load(os.path.join(HERE, "hk_methylium.npz")))
+    fchk = mg._Fchk(pos0=g["pos0"], energy0=g["energy0"], grad0=g["grad0"], hess0=g["hess0"], _m=g["masses"], nac0=g["nac0"])
+    pot = MolecularHarmonicPotential(fchk, fchk)
+    pot._origin = float(g["origin"])
+    res.update({"met_" + k: v for k, v in run("hk_methylium", pot, 10).items()})
+    np.savez_compressed(os.path.join(HERE, "hk_norms.npz"), **res)
+
+
+if __name__ == "__main__":
+    main()

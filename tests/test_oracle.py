@@ -105,3 +105,16 @@ def test_gdml_sum_conditioning():
     _, grad2, hess2 = gd.forward(r)
     assert 1e-10 < cases.rel_err(grad2.numpy(), grad.numpy()) < 1e-6
     assert cases.rel_err(hess2.numpy(), hess.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("name,tag", [("hk_as5_chi002", "as5"), ("hk_methylium", "met")])
+def test_norm_oracle_matches_reference(name, tag):
+    from oracle import norm_oracle
+    g, ref = cases.load(name), cases.load("hk_norms")
+    pot, prop = cases.oracle_potential(g), cases.oracle_propagator(g)
+    assert abs(norm_oracle.norm(prop) - float(ref[f"{tag}_norm_0"])) < 1e-12
+    for _ in range(int(ref[f"{tag}_nsteps"])):
+        prop.step(pot, float(g["dt"]))
+    n = int(ref[f"{tag}_nsteps"])
+    assert cases.rel_err(norm_oracle.coefficients(prop).numpy(), ref[f"{tag}_coeff_{n}"]) < 1e-11
+    assert abs(norm_oracle.norm(prop) - float(ref[f"{tag}_norm_{n}"])) < 1e-10
