@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
 }  // namespace
 
 int sc_launch_step_sd(const StepArgs &a, hipStream_t s);   // sc_hk_step_sd.hip
+int sc_launch_step_rw(const StepArgs &a, hipStream_t s);   // sc_hk_step_rw.hip
 
 static int step_threads(int D) { return D * D <= 256 ? 64 : 256; }
 
@@ -251,6 +252,10 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     if (fast) {
         const int dbg = (getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0) | (getenv("SC_DEBUG_FORCE_FIXUP") ? 0x400 : 0);
         StepArgs a{*pot, *st, *hk, dt, mode | dbg, energy_partials};
+        // SC_FAST_KERNEL=rw selects the row-wave layout (lane = column, full column pivoting, no fallback pass);
+        // measured slower on MI355X (12.2 ms vs 9.5 ms per step at D=60, n=1e5), kept as the reference variant
+        const char *which = getenv("SC_FAST_KERNEL");
+        if (which && which[0] == 'r') return sc_launch_step_rw(a, (hipStream_t)stream);
         const int rc = sc_launch_step_sd(a, (hipStream_t)stream);
         if (rc != SC_OK || !st->flags || (dbg & 0x100)) return rc;
         mode |= 0x200;      // fully pivoted fix-up of the trajectories the fast path flagged (normally none)
