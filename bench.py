@@ -157,7 +157,7 @@ def main():
                          "algorithmic_bytes_per_launch": abytes},
             "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(omega, chi, nac, q0, dt)
         print(json.dumps(out), flush=True)
     if world > 1:
