@@ -65,6 +65,7 @@ typedef struct sc_state {
     double *mono;
     double *c2;
     double *sgn;
+    double *work;           /* [n][4][D] scratch of the separable fast path: RK4 propagators of the monodromy rows */
     int32_t *flags;         /* [n], zero-initialised scratch: trajectories whose determinant the fast
                                path hands to the fully pivoted elimination (may be NULL) */
 } sc_state;

@@ -21,7 +21,7 @@ class sc_potential(C.Structure):
 class sc_state(C.Structure):
     _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("_pad", C.c_int32),
                 ("qp", c_double_p), ("act", c_double_p), ("mono", c_double_p),
-                ("c2", c_double_p), ("sgn", c_double_p), ("flags", C.c_void_p)]
+                ("c2", c_double_p), ("sgn", c_double_p), ("work", c_double_p), ("flags", C.c_void_p)]
 
 
 class sc_hk_consts(C.Structure):

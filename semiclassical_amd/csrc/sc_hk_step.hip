@@ -248,7 +248,7 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     const bool dense = pot->kind == SC_POT_HARMONIC_DENSE;
     if (!dense && pot->kind != SC_POT_MORSE && pot->kind != SC_POT_HARMONIC_SEP && pot->kind != SC_POT_EPS_MORSE)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown potential kind %d", pot->kind);
-    const bool fast = !dense && hk->diag && !getenv("SC_FORCE_GENERAL_STEP");
+    const bool fast = !dense && hk->diag && st->work && !getenv("SC_FORCE_GENERAL_STEP");
     if (fast) {
         const int dbg = (getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0) | (getenv("SC_DEBUG_FORCE_FIXUP") ? 0x400 : 0);
         StepArgs a{*pot, *st, *hk, dt, mode | dbg, energy_partials};

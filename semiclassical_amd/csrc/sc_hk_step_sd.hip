@@ -180,70 +180,32 @@ __device__ __forceinline__ bool eliminate_block(cplx (&m)[NR][NR], cplx &det, in
 template <int NR, int MINW>
 __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     __shared__ double prop[4 * 64];          // P_a = (p11, p12, p21, p22) of row a
-    __shared__ double imass[64];
     __shared__ double scl[4 * 64];           // st, 1/st, si, 1/si
     __shared__ cplx rowbuf[2][64];
     __shared__ PivotRecord pivrec[2];
     __shared__ int permseq[64];
     __shared__ int weak;
-    __shared__ double red[32];
 
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
     const int ti = tid >> 4, tj = tid & 15;
     const bool do_step = (A.mode & 0xff) == 0;
-    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
-
     if (tid < 64) {
         const bool in = tid < D;
         const double st = in ? A.hk.st[tid] : 1.0, si = in ? A.hk.si[tid] : 1.0;
         scl[tid] = st; scl[64 + tid] = 1.0 / st; scl[128 + tid] = si; scl[192 + tid] = 1.0 / si;
-        imass[tid] = (in && do_step) ? A.pot.inv_mass[tid] : 1.0;
         prop[tid] = 1.0; prop[64 + tid] = 0.0; prop[128 + tid] = 0.0; prop[192 + tid] = 1.0;
     }
     __syncthreads();
 
-    double esum = 0.0;
     for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
-        double *qp = A.st.qp + tr * 2 * D;
         double *M = A.st.mono + tr * 4 * (int64_t)DD;
         if (tid == 0) weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: debug, force the fallback (SC_DEBUG_FORCE_FIXUP)
 
         if (do_step) {
-            // ---------------- phase A ----------------
-            double red5[5] = {0, 0, 0, 0, 0};
-            if (tid < D) {
-                const double q = qp[tid], p = qp[D + tid], im = imass[tid];
-                const double c0 = A.pot.par0[tid], c1 = A.pot.par1 ? A.pot.par1[tid] : 0.0;
-                double v, g, h1, h2, h3, h4;
-                sep_eval(A.pot.kind, c0, c1, q, v, g, h1);
-                const double kq1 = p * im, kp1 = -g;
-                red5[0] = 0.5 * p * p * im - v;
-                const double q2 = q + hh * kq1, p2 = p + hh * kp1;
-                sep_eval(A.pot.kind, c0, c1, q2, v, g, h2);
-                const double kq2 = p2 * im, kp2 = -g;
-                red5[1] = 0.5 * p2 * p2 * im - v;
-                const double q3 = q + hh * kq2, p3 = p + hh * kp2;
-                sep_eval(A.pot.kind, c0, c1, q3, v, g, h3);
-                const double kq3 = p3 * im, kp3 = -g;
-                red5[2] = 0.5 * p3 * p3 * im - v;
-                const double q4 = q + dt * kq3, p4 = p + dt * kp3;
-                sep_eval(A.pot.kind, c0, c1, q4, v, g, h4);
-                const double kq4 = p4 * im, kp4 = -g;
-                red5[3] = 0.5 * p4 * p4 * im - v;
-                red5[4] = 0.5 * p4 * p4 * im + v;
-                qp[tid] = q + h6 * (kq1 + 2.0 * kq2 + 2.0 * kq3 + kq4);
-                qp[D + tid] = p + h6 * (kp1 + 2.0 * kp2 + 2.0 * kp3 + kp4);
-                // one RK4 step of du/dt = v/m, dv/dt = -h(t) u applied to the unit vectors
-                double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0;
-                rk4_pair(u1, v1, im, h1, h2, h3, h4, dt);
-                rk4_pair(u2, v2, im, h1, h2, h3, h4, dt);
-                prop[tid] = u1; prop[64 + tid] = u2; prop[128 + tid] = v1; prop[192 + tid] = v2;
-            }
-            block_sum<5>(red5, red);
-            if (tid == 0) {
-                A.st.act[tr] += h6 * (red5[0] + 2.0 * red5[1] + 2.0 * red5[2] + red5[3]);
-                esum += red5[4];
-            }
+            // row propagators P_a of this trajectory, computed by hk_modes_kernel ("phase A")
+            const double *pr = A.st.work + tr * 4 * (int64_t)D;
+            __syncthreads();
+            for (int i = tid; i < 4 * D; i += 256) prop[(i / D) * 64 + (i % D)] = pr[i];
             __syncthreads();
         }
 
@@ -340,7 +302,57 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         }
         __syncthreads();
     }
-    if (tid == 0 && A.epart) A.epart[blockIdx.x] = esum;
+}
+
+// "phase A" as its own launch: one wavefront per trajectory, lane = mode.  RK4 of (q_a, p_a) with the reference's
+// stage formula, the action and <T+V> at the k4 stage by wave reductions, and the 2x2 RK4 propagator P_a of the
+// monodromy rows (unit vectors pushed through the same stage formula) -> st.work[tr][4][D].
+__global__ __launch_bounds__(256) void hk_modes_kernel(StepArgs A) {
+    const int D = A.st.dim, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    __shared__ double wsum[4];
+    double esum = 0.0;
+    for (int64_t tr = (int64_t)blockIdx.x * 4 + wave; tr < A.st.n; tr += (int64_t)gridDim.x * 4) {
+        double *qp = A.st.qp + tr * 2 * D;
+        double *pr = A.st.work + tr * 4 * (int64_t)D;
+        double red5[5] = {0, 0, 0, 0, 0};
+        if (lane < D) {
+            const double q = qp[lane], p = qp[D + lane], im = A.pot.inv_mass[lane];
+            const double c0 = A.pot.par0[lane], c1 = A.pot.par1 ? A.pot.par1[lane] : 0.0;
+            double v, g, h1, h2, h3, h4;
+            sep_eval(A.pot.kind, c0, c1, q, v, g, h1);
+            const double kq1 = p * im, kp1 = -g;
+            red5[0] = 0.5 * p * p * im - v;
+            const double q2 = q + hh * kq1, p2 = p + hh * kp1;
+            sep_eval(A.pot.kind, c0, c1, q2, v, g, h2);
+            const double kq2 = p2 * im, kp2 = -g;
+            red5[1] = 0.5 * p2 * p2 * im - v;
+            const double q3 = q + hh * kq2, p3 = p + hh * kp2;
+            sep_eval(A.pot.kind, c0, c1, q3, v, g, h3);
+            const double kq3 = p3 * im, kp3 = -g;
+            red5[2] = 0.5 * p3 * p3 * im - v;
+            const double q4 = q + dt * kq3, p4 = p + dt * kp3;
+            sep_eval(A.pot.kind, c0, c1, q4, v, g, h4);
+            const double kq4 = p4 * im, kp4 = -g;
+            red5[3] = 0.5 * p4 * p4 * im - v;
+            red5[4] = 0.5 * p4 * p4 * im + v;
+            qp[lane] = q + h6 * (kq1 + 2.0 * kq2 + 2.0 * kq3 + kq4);
+            qp[D + lane] = p + h6 * (kp1 + 2.0 * kp2 + 2.0 * kp3 + kp4);
+            double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0;
+            rk4_pair(u1, v1, im, h1, h2, h3, h4, dt);
+            rk4_pair(u2, v2, im, h1, h2, h3, h4, dt);
+            pr[lane] = u1; pr[D + lane] = u2; pr[2 * D + lane] = v1; pr[3 * D + lane] = v2;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) red5[i] = wave_sum(red5[i]);
+        if (lane == 0) {
+            A.st.act[tr] += h6 * (red5[0] + 2.0 * red5[1] + 2.0 * red5[2] + red5[3]);
+            esum += red5[4];
+        }
+    }
+    if (lane == 0) wsum[wave] = esum;
+    __syncthreads();
+    if (threadIdx.x == 0 && A.epart) A.epart[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 }  // namespace
@@ -350,6 +362,7 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     const int D = a.st.dim, nr = (D + 15) / 16, grid = sc_step_grid(a.st.n, D);
     const char *occ_env = getenv("SC_SD_OCC");      // experiment knob: waves per SIMD the NR=4 kernel is compiled for
     const int occ = occ_env ? atoi(occ_env) : 4;
+    if ((a.mode & 0xff) == 0) hipLaunchKernelGGL(hk_modes_kernel, dim3(grid), dim3(256), 0, s, a);
     switch (nr) {
         case 1: hipLaunchKernelGGL((hk_step_sd_kernel<1, 4>), dim3(grid), dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((hk_step_sd_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a); break;

@@ -83,7 +83,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(so, name), name
     assert _lib.lib.sc_version() >= 1
     # struct sizes agree with the C layout (LP64): a mismatch would shift every pointer
-    assert ctypes.sizeof(_lib.sc_state) == 8 + 4 + 4 + 6 * 8
+    assert ctypes.sizeof(_lib.sc_state) == 8 + 4 + 4 + 7 * 8
     assert ctypes.sizeof(_lib.sc_potential) == 4 + 4 + 3 * 8 + 8 + 8
     assert ctypes.sizeof(_lib.sc_hk_consts) == 16 + 6 * 8
     assert ctypes.sizeof(_lib.sc_overlap_consts) == 8 + 5 * 8 + 8
