@@ -153,7 +153,8 @@ def main():
                        "sharding": f"{world} x {n} trajectories, one all-reduce of 4*K doubles per flush"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "hk_step_sd_kernel<4,4>", "kernel_ms": kern_ms,
+                         "kernel": "hk_step_sd_kernel<4,4,true> (+ its hk_modes_kernel pre-pass, same event bracket)",
+                         "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes},
             "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
         }

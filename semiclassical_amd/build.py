@@ -13,7 +13,6 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libsemiclassical_hip.so")
-STAMPS_LIB = os.path.join(HERE, "libsemiclassical_hip_stamps.so")   # diagnostic build, tools/lu_stamps.py
 
 
 def sources():
@@ -41,7 +40,4 @@ def build(force=False, verbose=True, extra=(), out=None):
 
 
 if __name__ == "__main__":
-    if "--stamps" in sys.argv:
-        build(force=True, extra=["-DSC_STAMPS"], out=STAMPS_LIB)
-    else:
-        build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv)

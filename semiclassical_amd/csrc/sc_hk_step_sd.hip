@@ -3,57 +3,34 @@
 //
 // One 256-thread workgroup per trajectory, grid-stride.  Threads form a 16 x 16 grid (ti, tj); thread (ti, tj)
 // owns the elements (a, b) = (16*ra + ti, 16*rb + tj), ra, rb < NR = ceil(D/16), of all four monodromy blocks
-// and of the complex prefactor matrix.  A wave covers four consecutive rows x 16 consecutive columns per slot,
-// i.e. every global access is a set of 128-byte row segments and the whole 4*D*D*8-byte state of the
-// trajectory is read once and written once.
+// and of the complex prefactor matrix.  Wave w holds the thread rows ti = w, w+4, w+8, w+12 (consecutive matrix
+// rows sit in DIFFERENT waves, which is what lets the elimination run as a pipeline); per slot a wave covers
+// four rows x 16 consecutive columns, i.e. every global access is a set of 128-byte row segments and the whole
+// 4*D*D*8-byte state of the trajectory is read once and written once.
 //
-//   phase A  threads a < D: RK4 of mode a (q_a, p_a); S and <T+V> by a workgroup reduction.  With a diagonal
-//            Hessian the monodromy elements (Mqq,Mpq)_ab and (Mqp,Mpp)_ab obey, for every b, the same linear
-//            2x2 system with the stage Hessians h_s[a]; its RK4 step is the 2x2 matrix P_a, obtained by
-//            pushing the unit vectors through the reference's stage formula.  P_a -> LDS.
+//   modes    (hk_modes_kernel, one wavefront per trajectory, lane = mode) RK4 of (q_a, p_a); S and <T+V> by wave
+//            reductions.  With a diagonal Hessian the monodromy elements (Mqq,Mpq)_ab and (Mqp,Mpp)_ab obey, for
+//            every b, the same linear 2x2 system with the stage Hessians h_s[a]; its RK4 step is the 2x2 matrix
+//            P_a, obtained by pushing the unit vectors through the reference's stage formula.  P_a -> st.work.
 //                                                               (propagators.py:86-119, 313-383; potentials.py)
 //   phase B  every (a,b): (Mqq,Mpq)' = P_a (Mqq,Mpq), (Mqp,Mpp)' = P_a (Mqp,Mpp), store back, and form
 //            mat_ab = 1/2[ st_a/si_b Mqq + si_b/st_a Mpp - i hbar st_a si_b Mqp + i/hbar Mpq/(st_a si_b) ]
-//            in registers
+//            in registers.  Element addresses are a wave-uniform base plus ONE per-thread 32-bit offset.
 //                                                                            (propagators.py:969-986)
 //   phase C  c2 = det(mat) by Gaussian elimination with the matrix held in REGISTERS (NR*NR complex per
 //            thread).  Rows are eliminated in natural order; the pivot COLUMN of row k is chosen by magnitude
 //            among the live columns of the diagonal 16-column block (threshold pivoting: the 16 consecutive
 //            lanes that own the row search it with integer keys and DPP rotations).  Because pivots stay inside
 //            the diagonal block, finished row AND column blocks drop out statically.  The owner scales the row
-//            by 1/pivot and publishes it through LDS (one barrier per elimination step); the pivot-column
-//            entries a thread needs sit in its own 16-lane group and are fetched with ds_bpermute.
+//            by 1/pivot and publishes it through LDS; the pivot-column entries a thread needs sit in its own
+//            16-lane group and are fetched with DPP row_newbcast.  Inside a block the four waves are NOT
+//            barrier-coupled: consumers poll a tag in the pivot record (see eliminate_block).
 //            If the best in-block pivot is more than 16x smaller than the largest live entry of the row, the
 //            trajectory is flagged (sc_state.flags) and its determinant is recomputed by the fully pivoted
 //            LDS elimination of sc_hk_step.hip in the same stream (never observed for HK matrices so far; the
 //            path is exercised by tests/test_hk_gpu.py::test_weak_pivot_fallback).
 //            Then the sqrt branch tracker.                   (torch.det, propagators.py:999, 1006-1052)
 #include "sc_common.h"
-
-#ifdef SC_STAMPS
-// diagnostic build only (tools/lu_stamps.py): per-wave cycle sums of the segments of an elimination step
-__device__ unsigned long long g_stamps[4][16];
-struct Stamps {
-    unsigned long long acc[16];
-    unsigned long long last;
-    int base;
-};
-#define STAMP(st, i)                                                                          \
-    do {                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        unsigned long long t_;                                                                \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-        __builtin_amdgcn_sched_barrier(0);                                                    \
-        (st).acc[(st).base + (i)] += t_ - (st).last;                                          \
-        (st).last = t_;                                                                       \
-    } while (0)
-extern "C" int sc_debug_read_stamps(unsigned long long *host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
-}
-#else
-struct Stamps {};
-#define STAMP(st, i) do { } while (0)
-#endif
 
 namespace {
 
@@ -62,17 +39,14 @@ __device__ __forceinline__ int dpp_mov_i32(int v) {
     return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
 }
 
-// max over the 16 lanes of a DPP row (row_ror 8, 4, 2, 1); every lane of the row gets the result
 __device__ __forceinline__ int row16_max_i32(int v) {
-    v = max(v, dpp_mov_i32<0x128>(v));
-    v = max(v, dpp_mov_i32<0x124>(v));
-    v = max(v, dpp_mov_i32<0x122>(v));
-    v = max(v, dpp_mov_i32<0x121>(v));
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
     return v;
-}
-
-__device__ __forceinline__ cplx row16_bcast(cplx v, int src) {
-    return c_make(__shfl(v.x, src, 16), __shfl(v.y, src, 16));
 }
 
 // value of `v` in lane `src` (wave-uniform index) as a wave-uniform scalar
@@ -96,108 +70,157 @@ struct PivotRecord {        // published by the owner of row k together with the
     int col, pad;           // pivot column
 };
 
-// rank-1 update of the rows below row k = 16*KB + kt with the scaled pivot row r; pivot column = (slot KB, lane pl).
-// (A wave-uniform switch over pl with DPP row_newbcast instead of ds_bpermute was measured SLOWER: the 16 code
-// paths miss the instruction cache, ~900 cycles per step in tools/lu_stamps.py.)
-template <int NR, int KB>
-__device__ __forceinline__ void eliminate(cplx (&m)[NR][NR], const cplx (&r)[NR], int kt, int ti, int pl, Stamps &st) {
-    cplx c[NR];
-#pragma unroll
-    for (int ra = KB; ra < NR; ++ra) c[ra] = row16_bcast(m[ra][KB], pl);
-    STAMP(st, 3);
-    if (ti <= kt) c[KB] = c_make(0.0, 0.0);
+// pivot-column entries of the NR-KB live row slots from lane PL of every 16-lane DPP row (row_newbcast: no LDS)
+template <int NR, int KB, int PL>
+__device__ __forceinline__ void column_bcast(const cplx (&m)[NR][NR], cplx (&c)[NR]) {
 #pragma unroll
     for (int ra = KB; ra < NR; ++ra) {
-#pragma unroll
-        for (int rb = KB; rb < NR; ++rb) m[ra][rb] = c_fnma(c[ra], r[rb], m[ra][rb]);
+        int xl, xh, yl, yh;
+        asm("s_nop 1\n\t"
+            "v_mov_b32_dpp %0, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %1, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %2, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b32_dpp %3, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+            : "=&v"(xl), "=&v"(xh), "=&v"(yl), "=&v"(yh)
+            : "v"(__double2loint(m[ra][KB].x)), "v"(__double2hiint(m[ra][KB].x)), "v"(__double2loint(m[ra][KB].y)),
+              "v"(__double2hiint(m[ra][KB].y)), "n"(PL));
+        c[ra] = c_make(__hiloint2double(xh, xl), __hiloint2double(yh, yl));
     }
 }
 
-// all elimination steps of the diagonal block KB; returns false when a zero pivot was met.
-// Within block KB only the columns of slot KB are consumed as pivots: `live` (per thread) says whether column
-// (slot KB, lane tj) is still available; slots rb > KB are untouched, slots rb < KB are finished.  Padded columns
-// (j >= D) hold zeros and can never win the magnitude search unless the whole row is zero (= singular).
+// the same with a wave-uniform run-time lane: a branch tree over the four bits of pl whose leaves hold only the moves
 template <int NR, int KB>
-__device__ __forceinline__ bool eliminate_block(cplx (&m)[NR][NR], cplx &det, int D, cplx (*rowbuf)[64],
-                                                PivotRecord *pivrec, int *permseq, int *weak, Stamps &st) {
-    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15, lane = tid & 63;
+__device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[NR], int pl) {
+    pl = __builtin_amdgcn_readfirstlane(pl);
+    if (pl & 8) {
+        if (pl & 4) {
+            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 15>(m, c); else column_bcast<NR, KB, 14>(m, c); }
+            else        { if (pl & 1) column_bcast<NR, KB, 13>(m, c); else column_bcast<NR, KB, 12>(m, c); }
+        } else {
+            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 11>(m, c); else column_bcast<NR, KB, 10>(m, c); }
+            else        { if (pl & 1) column_bcast<NR, KB, 9>(m, c); else column_bcast<NR, KB, 8>(m, c); }
+        }
+    } else {
+        if (pl & 4) {
+            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 7>(m, c); else column_bcast<NR, KB, 6>(m, c); }
+            else        { if (pl & 1) column_bcast<NR, KB, 5>(m, c); else column_bcast<NR, KB, 4>(m, c); }
+        } else {
+            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 3>(m, c); else column_bcast<NR, KB, 2>(m, c); }
+            else        { if (pl & 1) column_bcast<NR, KB, 1>(m, c); else column_bcast<NR, KB, 0>(m, c); }
+        }
+    }
+}
+
+// The 16 lanes that own row k = 16*KB + kt pick the pivot column among the live columns of the diagonal block,
+// scale the row by 1/pivot and publish it: row -> rowbuf[kt], pivot -> pivrec[kt], and LAST the record's tag
+// (= seq), which the consumers poll.  LDS operations of one wave execute in issue order, so a consumer that sees
+// the tag sees the row.  Runs inside `if (ti == kt)`.
+template <int NR, int KB>
+__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool live, int kt, int seq, cplx (*rowbuf)[64],
+                                                  PivotRecord *pivrec, int *permseq, int *weak) {
+    const int tid = threadIdx.x, tj = tid & 15, lane = tid & 63;
+    // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj)
+    const int blk = (__double2hiint(c_abs2(m[KB][KB])) & ~15) | (15 - tj);
+    int key_blk = live ? blk : -1;
+    // every lane inverts its own in-block candidate while the search runs; the winner's is used
+    const cplx myinv = c_inv_fast(m[KB][KB]);
+    key_blk = row16_max_i32(key_blk);
+    const int pl = 15 - (key_blk & 15);
+    const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | pl);
+    const cplx inv = c_make(readlane_f64(myinv.x, src), readlane_f64(myinv.y, src));
+    const bool keep = live && tj != pl;
+    const cplx r0 = c_mul(m[KB][KB], inv);
+    rowbuf[kt][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
+#pragma unroll
+    for (int rb = KB + 1; rb < NR; ++rb) rowbuf[kt][16 * rb + tj] = c_mul(m[KB][rb], inv);
+    if (tj == pl) {                                       // the winner publishes the pivot itself
+        pivrec[kt].re = m[KB][KB].x; pivrec[kt].im = m[KB][KB].y; pivrec[kt].col = 16 * KB + pl;
+        permseq[16 * KB + kt] = 16 * KB + pl;
+        __asm__ volatile("" ::: "memory");
+        __hip_atomic_store(&pivrec[kt].pad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __asm__ volatile("" ::: "memory");
+    // |pivot|^2 more than 2^8 below some |a_kj|^2 outside the block: the pivoted fallback redoes the trajectory
+    if (KB + 1 < NR) {
+        int key_out = -1;
+#pragma unroll
+        for (int rb = KB + 1; rb < NR; ++rb) key_out = max(key_out, __double2hiint(c_abs2(m[KB][rb])));
+        if ((key_out & ~15) - (key_blk & ~15) > (8 << 20)) *weak = 1;
+    }
+}
+
+// All elimination steps of the diagonal block KB.  Within block KB only the columns of slot KB are consumed as
+// pivots: `live` (per thread) says whether column (slot KB, lane tj) is still available; slots rb > KB are untouched,
+// slots rb < KB are finished.  Padded columns (j >= D) hold zeros and can never win the magnitude search unless the
+// whole row is zero (= singular: flagged, the arithmetic runs on with inf/nan and the result is discarded).
+// No barrier inside the block: the four waves run the 16 steps as a dataflow pipeline.  A wave waits for row kt by
+// polling the tag of pivrec[kt] (reading the record and the row in the same batch), fetches the pivot-column entries
+// with DPP, updates row slot KB first so that the 16 lanes owning row kt+1 can search and publish at once, and only
+// then does the rest of its rank-1 update.  The chain owner(kt) -> owner(kt+1) is the critical path; the bulk of
+// the update floats beside it.  One barrier per block protects the reuse of the 16 row buffers.
+template <int NR, int KB>
+__device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bool &singular, int D, int seq,
+                                                cplx (*rowbuf)[64], PivotRecord *pivrec, int *permseq, int *weak) {
+    const int tid = threadIdx.x, ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;
     const int nk = min(16, D - 16 * KB);
     bool live = 16 * KB + tj < D;
+    __syncthreads();
+    if (ti == 0) publish_pivot_row<NR, KB>(m, live, 0, seq, rowbuf, pivrec, permseq, weak);
     for (int kt = 0; kt < nk; ++kt) {
-        const int k = 16 * KB + kt;
-        const int par = k & 1;
-#ifdef SC_STAMPS
-        st.base = ((tid >> 6) == (kt >> 2)) ? 0 : 8;      // owner wave of this step or not
-        STAMP(st, 7);                                    // (restart the clock)
-#endif
-        if (ti == kt) {
-            // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj); in-block candidates and the rest of the row
-            const int blk = (__double2hiint(c_abs2(m[KB][KB])) & ~15) | (15 - tj);
-            int key_blk = live ? blk : -1, key_out = -1;
-#pragma unroll
-            for (int rb = KB + 1; rb < NR; ++rb) key_out = max(key_out, __double2hiint(c_abs2(m[KB][rb])));
-            // every lane inverts its own in-block candidate while the search runs; the winner's is used
-            const cplx myinv = c_inv_fast(m[KB][KB]);
-            key_blk = row16_max_i32(key_blk);
-            const int pl = 15 - (key_blk & 15);
-            // pivot value and inverse: lane pl of this 16-lane group, as wave-uniform scalars
-            const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | pl);
-            const cplx piv = c_make(readlane_f64(m[KB][KB].x, src), readlane_f64(m[KB][KB].y, src));
-            const cplx inv = c_make(readlane_f64(myinv.x, src), readlane_f64(myinv.y, src));
-            const bool keep = live && tj != pl;
-            const cplx r0 = c_mul(m[KB][KB], inv);
-            rowbuf[par][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
-#pragma unroll
-            for (int rb = KB + 1; rb < NR; ++rb) rowbuf[par][16 * rb + tj] = c_mul(m[KB][rb], inv);
-            // |pivot|^2 more than 2^8 below some |a_kj|^2 outside the block: the pivoted fallback redoes it
-            const unsigned long long any_small = __ballot((key_out & ~15) - (key_blk & ~15) > (8 << 20));
-            if (tj == 0) {
-                PivotRecord rec;
-                rec.re = piv.x; rec.im = piv.y; rec.col = 16 * KB + pl; rec.pad = 0;
-                pivrec[par] = rec;
-                permseq[k] = 16 * KB + pl;
-                if (any_small) *weak = 1;
-            }
-        }
-        STAMP(st, 0);
-        __syncthreads();
-        STAMP(st, 1);
-        const PivotRecord rec = pivrec[par];
+        double re, im;
+        int col;
         cplx r[NR];
+        for (;;) {
+            const int tag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pivrec[kt].pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            __asm__ volatile("" ::: "memory");
+            re = pivrec[kt].re; im = pivrec[kt].im; col = pivrec[kt].col;
 #pragma unroll
-        for (int rb = KB; rb < NR; ++rb) r[rb] = rowbuf[par][16 * rb + tj];
-        STAMP(st, 2);
-        if (rec.re == 0.0 && rec.im == 0.0) return false;
-        if (tid < 64) det = c_mul(det, c_make(rec.re, rec.im));
-        const int pl = rec.col & 15;
+            for (int rb = KB; rb < NR; ++rb) r[rb] = rowbuf[kt][16 * rb + tj];
+            __asm__ volatile("" ::: "memory");
+            if (tag == seq) break;
+        }
+        singular = singular || (re == 0.0 && im == 0.0);
+        if (tid < 64) det = c_mul(det, c_make(re, im));
+        const int pl = col & 15;
         live = live && tj != pl;
-        eliminate<NR, KB>(m, r, kt, ti, pl, st);
-        STAMP(st, 4);
+        cplx c[NR];
+        column_fetch<NR, KB>(m, c, pl);
+        if (ti <= kt) c[KB] = c_make(0.0, 0.0);
+#pragma unroll
+        for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
+        if (kt + 1 < nk && ti == kt + 1) publish_pivot_row<NR, KB>(m, live, kt + 1, seq, rowbuf, pivrec, permseq, weak);
+#pragma unroll
+        for (int ra = KB + 1; ra < NR; ++ra) {
+#pragma unroll
+            for (int rb = KB; rb < NR; ++rb) m[ra][rb] = c_fnma(c[ra], r[rb], m[ra][rb]);
+        }
     }
-    return true;
 }
 
-template <int NR, int MINW>
+template <int NR, int MINW, bool STEP>
 __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     __shared__ double prop[4 * 64];          // P_a = (p11, p12, p21, p22) of row a
     __shared__ double scl[4 * 64];           // st, 1/st, si, 1/si
-    __shared__ cplx rowbuf[2][64];
-    __shared__ PivotRecord pivrec[2];
+    __shared__ cplx rowbuf[16][64];
+    __shared__ PivotRecord pivrec[16];
     __shared__ int permseq[64];
     __shared__ int weak;
 
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;
-    const bool do_step = (A.mode & 0xff) == 0;
+    const int ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;   // consecutive rows sit in different waves
+    constexpr bool do_step = STEP;                   // false: prefactor and tracker initialisation only (t = 0)
+    const unsigned toff = (unsigned)(ti * D + tj);      // element (ti, tj) of a D x D plane
     if (tid < 64) {
         const bool in = tid < D;
         const double st = in ? A.hk.st[tid] : 1.0, si = in ? A.hk.si[tid] : 1.0;
+        if (tid < 16) pivrec[tid].pad = 0;
         scl[tid] = st; scl[64 + tid] = 1.0 / st; scl[128 + tid] = si; scl[192 + tid] = 1.0 / si;
         prop[tid] = 1.0; prop[64 + tid] = 0.0; prop[128 + tid] = 0.0; prop[192 + tid] = 1.0;
     }
     __syncthreads();
 
-    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+    int seq0 = 0;                                  // tags of this workgroup's pivot records: unique per (trajectory, block)
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += 4) {
         double *M = A.st.mono + tr * 4 * (int64_t)DD;
         if (tid == 0) weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: debug, force the fallback (SC_DEBUG_FORCE_FIXUP)
 
@@ -221,25 +244,25 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
             double vqq[NR], vqp[NR], vpq[NR], vpp[NR];
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
-                const int b = 16 * rb + tj;
-                const bool ok = rowok && b < D;
-                const int e = a * D + b;
-                vqq[rb] = ok ? M[e] : 0.0;
-                vqp[rb] = ok ? M[DD + e] : 0.0;
-                vpq[rb] = ok ? M[2 * DD + e] : 0.0;
-                vpp[rb] = ok ? M[3 * DD + e] : 0.0;
+                const bool ok = rowok && 16 * rb + tj < D;
+                // wave-uniform element base (scalar registers) + one per-thread 32-bit offset
+                const double *pe = M + (16 * ra * D + 16 * rb);
+                vqq[rb] = ok ? pe[toff] : 0.0;
+                vqp[rb] = ok ? pe[DD + toff] : 0.0;
+                vpq[rb] = ok ? pe[2 * DD + toff] : 0.0;
+                vpp[rb] = ok ? pe[3 * DD + toff] : 0.0;
             }
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
                 const int b = 16 * rb + tj;
                 const bool ok = rowok && b < D;
-                const int e = a * D + b;
+                double *pe = M + (16 * ra * D + 16 * rb);
                 double mqq = vqq[rb], mqp = vqp[rb], mpq = vpq[rb], mpp = vpp[rb];
                 if (do_step) {
                     const double nqq = fma(p12, mpq, p11 * mqq), npq = fma(p22, mpq, p21 * mqq);
                     const double nqp = fma(p12, mpp, p11 * mqp), npp = fma(p22, mpp, p21 * mqp);
                     mqq = nqq; mpq = npq; mqp = nqp; mpp = npp;
-                    if (ok) { M[e] = mqq; M[DD + e] = mqp; M[2 * DD + e] = mpq; M[3 * DD + e] = mpp; }
+                    if (ok) { pe[toff] = mqq; pe[DD + toff] = mqp; pe[2 * DD + toff] = mpq; pe[3 * DD + toff] = mpp; }
                 }
                 const int bl = b & 63;
                 const double sib = scl[128 + bl], isib = scl[192 + bl];
@@ -247,32 +270,17 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                                         0.5 * (-SC_HBAR * sta * sib * mqp + (1.0 / SC_HBAR) * ista * isib * mpq))
                                : c_make(0.0, 0.0);
             }
-#ifdef SC_PHASEB_FENCE
-            // one row slot of loads in flight at a time (register budget at 4 waves/SIMD)
-            __asm__ volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
 
         // ---------------- phase C: determinant in registers ----------------
         cplx det = c_make(1.0, 0.0);
         bool singular = false;
-        Stamps st;
-#ifdef SC_STAMPS
-        for (int i = 0; i < 16; ++i) st.acc[i] = 0;
-        st.last = 0; st.base = 0;
-#endif
         if (!(A.mode & 0x100)) {                 // 0x100: debug, skip the elimination (SC_DEBUG_SKIP_LU)
-            bool ok = eliminate_block<NR, 0>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
-            if (NR > 1 && ok) ok = eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
-            if (NR > 2 && ok) ok = eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
-            if (NR > 3 && ok) ok = eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, D, rowbuf, pivrec, permseq, &weak, st);
-            singular = !ok;
+            eliminate_block<NR, 0>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, &weak);
+            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, &weak);
+            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, &weak);
+            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, &weak);
         }
-#ifdef SC_STAMPS
-        if (blockIdx.x == 0 && (tid & 63) == 0)
-            for (int i = 0; i < 16; ++i) g_stamps[tid >> 6][i] = st.acc[i];
-#endif
         __syncthreads();
         if (tid == 0 && weak && A.st.flags && !(A.mode & 0x100)) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
@@ -363,15 +371,22 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     const char *occ_env = getenv("SC_SD_OCC");      // experiment knob: waves per SIMD the NR=4 kernel is compiled for
     const int occ = occ_env ? atoi(occ_env) : 4;
     if ((a.mode & 0xff) == 0) hipLaunchKernelGGL(hk_modes_kernel, dim3(grid), dim3(256), 0, s, a);
+    const bool step = (a.mode & 0xff) == 0;
+#define SC_LAUNCH_SD(NR_, OCC_)                                                                                \
+    do {                                                                                                       \
+        if (step) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true>), dim3(grid), dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false>), dim3(grid), dim3(256), 0, s, a);        \
+    } while (0)
     switch (nr) {
-        case 1: hipLaunchKernelGGL((hk_step_sd_kernel<1, 4>), dim3(grid), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((hk_step_sd_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL((hk_step_sd_kernel<3, 3>), dim3(grid), dim3(256), 0, s, a); break;
+        case 1: SC_LAUNCH_SD(1, 4); break;
+        case 2: SC_LAUNCH_SD(2, 4); break;
+        case 3: SC_LAUNCH_SD(3, 4); break;
         default:
-            if (occ >= 4) hipLaunchKernelGGL((hk_step_sd_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a);
-            else if (occ == 3) hipLaunchKernelGGL((hk_step_sd_kernel<4, 3>), dim3(grid), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((hk_step_sd_kernel<4, 2>), dim3(grid), dim3(256), 0, s, a);
+            if (occ >= 4) SC_LAUNCH_SD(4, 4);
+            else if (occ == 3) SC_LAUNCH_SD(4, 3);
+            else SC_LAUNCH_SD(4, 2);
             break;
     }
+#undef SC_LAUNCH_SD
     return sc_check_launch("sc_hk_step (separable/diagonal fast path)");
 }
