@@ -70,45 +70,62 @@ struct PivotRecord {        // published by the owner of row k together with the
     int col, pad;           // pivot column
 };
 
-// pivot-column entries of the NR-KB live row slots from lane PL of every 16-lane DPP row (row_newbcast: no LDS)
-template <int NR, int KB, int PL>
-__device__ __forceinline__ void column_bcast(const cplx (&m)[NR][NR], cplx (&c)[NR]) {
-#pragma unroll
-    for (int ra = KB; ra < NR; ++ra) {
-        int xl, xh, yl, yh;
-        asm("s_nop 1\n\t"
-            "v_mov_b32_dpp %0, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %1, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %2, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_mov_b32_dpp %3, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
-            : "=&v"(xl), "=&v"(xh), "=&v"(yl), "=&v"(yh)
-            : "v"(__double2loint(m[ra][KB].x)), "v"(__double2hiint(m[ra][KB].x)), "v"(__double2loint(m[ra][KB].y)),
-              "v"(__double2hiint(m[ra][KB].y)), "n"(PL));
-        c[ra] = c_make(__hiloint2double(xh, xl), __hiloint2double(yh, yl));
-    }
+// Pivot-column entries of the N = NR-KB live row slots from lane pl (wave-uniform, run-time) of every 16-lane DPP
+// row: DPP row_newbcast (no LDS traffic; 64-bit DPP moves exist on gfx90a+ exactly for this control).  The lane is
+// an immediate of the instruction, so there are 16 leaves of 2N moves each and a computed jump (s_setpc_b64) to
+// the leaf of pl; a leaf is 2N*8 + 4 bytes (s_branch to the end).
+#define SC_DPP_MOV(o, i, P) "v_mov_b64_dpp %[" #o "], %[" #i "] row_newbcast:" #P " row_mask:0xf bank_mask:0xf\n\t"
+#define SC_LEAF1(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) "s_branch .Lend_%=\n\t"
+#define SC_LEAF2(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
+    "s_branch .Lend_%=\n\t"
+#define SC_LEAF3(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
+    SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) "s_branch .Lend_%=\n\t"
+#define SC_LEAF4(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
+    SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) SC_DPP_MOV(ox3, ix3, P) SC_DPP_MOV(oy3, iy3, P) "s_branch .Lend_%=\n\t"
+#define SC_LEAVES(L) L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15)
+#define SC_JUMP(BYTES)                                                                           \
+    "s_getpc_b64 vcc\n"                                                                          \
+    ".Lbase_%=:\n\t"                                                                             \
+    "s_mul_i32 %[t], %[pl], " #BYTES "\n\t"                                                      \
+    "s_add_u32 vcc_lo, vcc_lo, %[t]\n\t"                                                         \
+    "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"                                                           \
+    "s_add_u32 vcc_lo, vcc_lo, .Lleaf0_%=-.Lbase_%=\n\t"                                         \
+    "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"                                                           \
+    "s_setpc_b64 vcc\n"                                                                          \
+    ".Lleaf0_%=:\n\t"
+#define SC_IN(n) [ix##n] "v"(m##n.x), [iy##n] "v"(m##n.y)
+#define SC_OUT(n) [ox##n] "=&v"(c##n.x), [oy##n] "=&v"(c##n.y)
+
+__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx &c0) {
+    int t;
+    asm volatile(SC_JUMP(20) SC_LEAVES(SC_LEAF1) ".Lend_%=:\n" : SC_OUT(0), [t] "=&s"(t) : SC_IN(0), [pl] "s"(pl) : "vcc", "scc");
+}
+__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx &c0, cplx &c1) {
+    int t;
+    asm volatile(SC_JUMP(36) SC_LEAVES(SC_LEAF2) ".Lend_%=:\n"
+                 : SC_OUT(0), SC_OUT(1), [t] "=&s"(t) : SC_IN(0), SC_IN(1), [pl] "s"(pl) : "vcc", "scc");
+}
+__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx m2, cplx &c0, cplx &c1, cplx &c2) {
+    int t;
+    asm volatile(SC_JUMP(52) SC_LEAVES(SC_LEAF3) ".Lend_%=:\n"
+                 : SC_OUT(0), SC_OUT(1), SC_OUT(2), [t] "=&s"(t) : SC_IN(0), SC_IN(1), SC_IN(2), [pl] "s"(pl) : "vcc", "scc");
+}
+__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx m2, cplx m3, cplx &c0, cplx &c1, cplx &c2,
+                                               cplx &c3) {
+    int t;
+    asm volatile(SC_JUMP(68) SC_LEAVES(SC_LEAF4) ".Lend_%=:\n"
+                 : SC_OUT(0), SC_OUT(1), SC_OUT(2), SC_OUT(3), [t] "=&s"(t)
+                 : SC_IN(0), SC_IN(1), SC_IN(2), SC_IN(3), [pl] "s"(pl) : "vcc", "scc");
 }
 
-// the same with a wave-uniform run-time lane: a branch tree over the four bits of pl whose leaves hold only the moves
 template <int NR, int KB>
 __device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[NR], int pl) {
     pl = __builtin_amdgcn_readfirstlane(pl);
-    if (pl & 8) {
-        if (pl & 4) {
-            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 15>(m, c); else column_bcast<NR, KB, 14>(m, c); }
-            else        { if (pl & 1) column_bcast<NR, KB, 13>(m, c); else column_bcast<NR, KB, 12>(m, c); }
-        } else {
-            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 11>(m, c); else column_bcast<NR, KB, 10>(m, c); }
-            else        { if (pl & 1) column_bcast<NR, KB, 9>(m, c); else column_bcast<NR, KB, 8>(m, c); }
-        }
-    } else {
-        if (pl & 4) {
-            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 7>(m, c); else column_bcast<NR, KB, 6>(m, c); }
-            else        { if (pl & 1) column_bcast<NR, KB, 5>(m, c); else column_bcast<NR, KB, 4>(m, c); }
-        } else {
-            if (pl & 2) { if (pl & 1) column_bcast<NR, KB, 3>(m, c); else column_bcast<NR, KB, 2>(m, c); }
-            else        { if (pl & 1) column_bcast<NR, KB, 1>(m, c); else column_bcast<NR, KB, 0>(m, c); }
-        }
-    }
+    if constexpr (NR - KB == 1) column_fetch_n(pl, m[KB][KB], c[KB]);
+    if constexpr (NR - KB == 2) column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], c[KB], c[KB + 1]);
+    if constexpr (NR - KB == 3) column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], c[KB], c[KB + 1], c[KB + 2]);
+    if constexpr (NR - KB == 4)
+        column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], m[KB + 3][KB], c[KB], c[KB + 1], c[KB + 2], c[KB + 3]);
 }
 
 // The 16 lanes that own row k = 16*KB + kt pick the pivot column among the live columns of the diagonal block,
