@@ -24,14 +24,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 
-def as60_model():
-    """synthetic 60-mode AS model, SURVEY.md section 8d config 2"""
+def as60_model(dim=60):
+    """synthetic 60-mode AS model, SURVEY.md section 8d config 2 (other `dim` only for the tools/ experiments)"""
     from semiclassical_amd import units
     rng = np.random.default_rng(60)
-    omega_cm = np.linspace(160.0, 3300.0, 60)
-    S = rng.uniform(0, 0.1, 60) * rng.choice([-1, 1], 60)
-    nac = rng.normal(0, 1e-4, 60)
-    chi = np.full(60, 0.02)
+    omega_cm = np.linspace(160.0, 3300.0, dim)
+    S = rng.uniform(0, 0.1, dim) * rng.choice([-1, 1], dim)
+    nac = rng.normal(0, 1e-4, dim)
+    chi = np.full(dim, 0.02)
     omega = torch.from_numpy(omega_cm / units.hartree_to_wavenumbers)
     S, nac, chi = torch.from_numpy(S), torch.from_numpy(nac), torch.from_numpy(chi)
     q0 = torch.sqrt(2.0 * abs(S) / omega) * torch.sign(S)

@@ -223,6 +223,12 @@ int sc_pair_sum(const double *X1, const double *Y1, int32_t K1, const double *X2
                 const double *rs, const double *ib, const double *ik, const double *wb, const double *wk,
                 int64_t n, double *partials, void *stream);
 
+/* Frozen-Gaussian wavefunction on a spatial grid behind HermanKlukPropagator.wavefunction() (propagators.py:252-292,
+ * 688-732):  phi[k] = fac sum_n v_n exp(-1/2 |Lx_k - Lq_n|^2 + i (p_n.x_k - pq_n)),  L = Gamma_t^(1/2).
+ * LqT, PT [D][n] (trajectory index fastest), pq [n], v [n] complex, Lx, X [nx][D], phi [nx] complex. */
+int sc_grid_sum(const double *LqT, const double *PT, const double *pq, const double *v, int64_t n, int32_t D,
+                const double *Lx, const double *X, int32_t nx, double fac, double *phi, void *stream);
+
 /* Energy-conservation guard on the device, reference propagators.py:385-398 (check_energy_conservation).
  * elog[4] = { <T+V>(t-dt), <T+V>(t), largest |change| seen so far, number of steps logged }.
  * The mean of this step is formed from energy_partials; the host raises the reference's RuntimeError when

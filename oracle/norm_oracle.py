@@ -1,4 +1,5 @@
-"""CPU oracle of HermanKlukPropagator.coefficients() / norm() (reference propagators.py:657-686, 734-782).
+"""CPU oracle of HermanKlukPropagator.coefficients() / norm() / wavefunction()
+(reference propagators.py:657-686, 734-782, 688-732 with CoherentStatesWavefunction :243-292).
 
 TEST INFRASTRUCTURE ONLY (see oracle/sc_oracle.py).  Pinned by tests/golden/hk_norms.npz, produced by the reference.
 """
@@ -28,3 +29,18 @@ def norm(prop, chunk=1000):
         for qj, pj, vj in zip(torch.chunk(q, nchunk, dim=1), torch.chunk(p, nchunk, dim=1), torch.chunk(v, nchunk, dim=0)):
             total += torch.einsum('i,ij,j', vi.conj(), prop.csott(qi, pi, qj, pj), vj)
     return torch.sqrt(total.real).item()
+
+
+def wavefunction(prop, x):
+    """psi(x_k) = sum_n v_n (det'Gt / pi^rank)^(1/4) exp(-1/2 (x-q_n)^T Gt (x-q_n) + i/hbar p_n.(x-q_n)),  x (dim,nx)
+    (reference propagators.py:274-292, 722-732; the chunking over the grid does not change the sums)"""
+    x = torch.as_tensor(x, dtype=torch.float64)
+    Gt = prop.Gamma_t
+    e = torch.linalg.eigvalsh(Gt)
+    keep = abs(e) > orc.ZERO
+    fac = (torch.prod(e[keep]) / np.pi ** int(torch.count_nonzero(keep))) ** 0.25
+    q, p = prop.current_positions_and_momenta()
+    v = coefficients(prop)
+    dx = x.unsqueeze(1) - q.unsqueeze(2)                                   # (dim, ntraj, nx)
+    expo = -0.5 * torch.einsum('inx,ij,jnx->nx', dx, Gt, dx) + 1j / hbar * torch.einsum('in,inx->nx', p, dx)
+    return torch.sum(v.unsqueeze(1) * fac * torch.exp(expo), 0).numpy()

@@ -86,7 +86,79 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs A) {
     }
 }
 
+// Frozen-Gaussian wavefunction on a spatial grid (reference propagators.py:252-292, 688-732)
+//   phi(x_k) = fac sum_n v_n exp( -1/2 |L x_k - L q_n|^2 + i ( p_n . x_k - p_n . q_n ) ),   L = Gamma_t^(1/2) (symmetric),
+// i.e. the quadratic form (x-q)^T Gamma_t (x-q) written as a squared distance in the L-transformed coordinates, which
+// the host prepares once per call (LqT, PmT are [D][n], trajectory index fastest: coalesced; pq[n] = p_n . q_n).
+// One workgroup owns GX grid points (their L x and x staged in LDS) and strides over the trajectories.
+#define GX 4
+struct GridArgs {
+    const double *LqT, *PmT, *pq, *v;      // [D][n], [D][n], [n], [n] complex
+    int64_t n;
+    int D, nx;
+    const double *Lx, *X;                 // [nx][D]
+    double fac;
+    double *phi;                          // [nx] complex
+};
+
+__global__ __launch_bounds__(256) void grid_sum_kernel(GridArgs A) {
+    extern __shared__ double gs[];        // Lx[GX][D], X[GX][D]
+    __shared__ double red[32];
+    const int tid = threadIdx.x, D = A.D, k0 = blockIdx.x * GX;
+    for (int e = tid; e < GX * D; e += 256) {
+        const int g = e / D, a = e - g * D;
+        const bool in = k0 + g < A.nx;
+        gs[e] = in ? A.Lx[(size_t)(k0 + g) * D + a] : 0.0;
+        gs[GX * D + e] = in ? A.X[(size_t)(k0 + g) * D + a] : 0.0;
+    }
+    __syncthreads();
+    double acc[2 * GX];
+#pragma unroll
+    for (int g = 0; g < 2 * GX; ++g) acc[g] = 0.0;
+    for (int64_t i = tid; i < A.n; i += 256) {
+        double e2[GX], ph[GX];
+        const double pq = A.pq[i];
+#pragma unroll
+        for (int g = 0; g < GX; ++g) { e2[g] = 0.0; ph[g] = -pq; }
+        for (int a = 0; a < D; ++a) {
+            const double lq = A.LqT[(size_t)a * A.n + i], p = A.PmT[(size_t)a * A.n + i];
+#pragma unroll
+            for (int g = 0; g < GX; ++g) {
+                const double d = gs[g * D + a] - lq;
+                e2[g] = fma(d, d, e2[g]);
+                ph[g] = fma(p, gs[GX * D + g * D + a], ph[g]);
+            }
+        }
+        const cplx v = ((const cplx *)A.v)[i];
+#pragma unroll
+        for (int g = 0; g < GX; ++g) {
+            const cplx t = c_mul(v, c_exp(c_make(-0.5 * e2[g], ph[g])));
+            acc[2 * g] += t.x; acc[2 * g + 1] += t.y;
+        }
+    }
+    block_sum<2 * GX>(acc, red);
+    if (tid == 0) {
+#pragma unroll
+        for (int g = 0; g < GX; ++g)
+            if (k0 + g < A.nx) {
+                A.phi[2 * (size_t)(k0 + g)] = A.fac * acc[2 * g];
+                A.phi[2 * (size_t)(k0 + g) + 1] = A.fac * acc[2 * g + 1];
+            }
+    }
+}
+
 }  // namespace
+
+extern "C" int sc_grid_sum(const double *LqT, const double *PmT, const double *pq, const double *v, int64_t n, int32_t D,
+                           const double *Lx, const double *X, int32_t nx, double fac, double *phi, void *stream) {
+    if (!LqT || !PmT || !pq || !v || !Lx || !X || !phi) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_grid_sum: null argument");
+    if (D < 1 || D > 512) return sc_fail(SC_ERR_UNSUPPORTED, "sc_grid_sum: D=%d outside 1..512", D);
+    if (nx <= 0 || n <= 0) return SC_OK;
+    GridArgs a{LqT, PmT, pq, v, n, D, nx, Lx, X, fac, phi};
+    hipLaunchKernelGGL(grid_sum_kernel, dim3((unsigned)((nx + GX - 1) / GX)), dim3(256), 2 * GX * D * sizeof(double),
+                       (hipStream_t)stream, a);
+    return sc_check_launch("sc_grid_sum");
+}
 
 extern "C" int64_t sc_pair_sum_tiles(int64_t n) {
     const int64_t t = (n + PT - 1) / PT;

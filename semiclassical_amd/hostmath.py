@@ -35,6 +35,19 @@ def sym_sqrtm(A):
     return root, iroot
 
 
+def psd_sqrt_real(A):
+    """real symmetric L with L L = A for a symmetric non-negative A (eigenvalues below zero by rounding are clamped)"""
+    w, V = _eigh(A)
+    return torch.einsum('ij,j,kj->ik', V, torch.sqrt(torch.clamp(w, min=0.0)), V)
+
+
+def wavepacket_norm_factor(G):
+    """(det'(G) / pi^rank)^(1/4), det' over the non-zero eigenvalues.  propagators.py:244-250, 284"""
+    e, _ = _eigh(G)
+    keep = abs(e) > ZERO
+    return float((torch.prod(e[keep]) / np.pi ** int(torch.count_nonzero(keep))) ** 0.25)
+
+
 def is_symmetric_non_negative(A, eps=1.0e-6):
     """propagators.py:61-82"""
     if torch.sum(abs(A - A.T)) / torch.sum(abs(A)) > eps:

@@ -415,6 +415,30 @@ class HermanKlukPropagator(object):
         check(lib.sc_reduce_slot(ptr(partials), int(tiles), None, 0, 1.0, ptr(slot), s))
         return float(torch.sqrt(slot[0]).item())
 
+    def wavefunction(self, x):
+        """frozen-Gaussian wavefunction psi(x,t) on a spatial grid x (dim,nx) -> complex ndarray (nx,)
+        (reference propagators.py:688-732 with CoherentStatesWavefunction :243-292)"""
+        x = torch.as_tensor(x, dtype=F64)
+        d, nx = x.shape
+        assert d == self.dim, "spatial grid has wrong dimensions"
+        dev, n = self.device, self.ntraj
+        L = hostmath.psd_sqrt_real(self._Gt)                  # (x-q)^T Gt (x-q) = |L (x-q)|^2
+        fac = hostmath.wavepacket_norm_factor(self._Gt)
+        Ld = L.to(dev)
+        q, p = self._qp[:, :d], self._qp[:, d:]
+        LqT = (Ld @ q.T).contiguous()
+        PT = p.T.contiguous()
+        pq = ((p * q).sum(1) / hbar).contiguous()
+        if hbar != 1.0:
+            PT = PT / hbar
+        X = x.T.contiguous().to(dev)
+        Lx = (X @ Ld.T).contiguous()
+        v = self.coefficients().contiguous()
+        phi = torch.zeros(nx, dtype=C128, device=dev)
+        check(lib.sc_grid_sum(ptr(LqT), ptr(PT), ptr(pq), ptr(v), n, d, ptr(Lx), ptr(X), nx, fac, ptr(phi),
+                              self._stream()))
+        return phi.cpu().numpy()
+
     def _get_signs_of_sqrt(self, key):
         if key != "prefactorC":
             logger.error(f"Apparently the sign of the square root of the quantity '{key}' is not being tracked.")

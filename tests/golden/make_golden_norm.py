@@ -24,10 +24,16 @@ def run(name, potential, nsteps):
     prop = HermanKlukPropagator(T(g["Gamma_i"]), T(g["Gamma_t"]))
     prop.initial_conditions(T(g["q0"]), T(g["p0"]), T(g["Gamma_0"]), ntraj=g["zi"].shape[1])
     assert np.array_equal(prop.zi.numpy(), g["zi"])          # same seed => same initial conditions as the golden
-    out = {"norm_0": prop.norm(), "coeff_0": prop.coefficients().numpy()}
+    # spatial grid for wavefunction(): points on the segment between the centre q0 and the mean final position, and beyond
+    rng = np.random.default_rng(7)
+    d = g["q0"].shape[0]
+    xgrid = g["q0"][:, None] + 0.3 * rng.standard_normal((d, 9)) / np.sqrt(np.maximum(np.diag(g["Gamma_t"]), 1e-3))[:, None]
+    out = {"norm_0": prop.norm(), "coeff_0": prop.coefficients().numpy(), "xgrid": xgrid,
+           "psi_0": prop.wavefunction(T(xgrid))}
     for _ in range(nsteps):
         prop.step(potential, float(g["dt"]))
-    out.update({"nsteps": nsteps, f"norm_{nsteps}": prop.norm(), f"coeff_{nsteps}": prop.coefficients().numpy()})
+    out.update({"nsteps": nsteps, f"norm_{nsteps}": prop.norm(), f"coeff_{nsteps}": prop.coefficients().numpy(),
+                f"psi_{nsteps}": prop.wavefunction(T(xgrid))})
     print(name, out["norm_0"], out[f"norm_{nsteps}"])
     return out
 

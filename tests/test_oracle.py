@@ -113,8 +113,10 @@ def test_norm_oracle_matches_reference(name, tag):
     g, ref = cases.load(name), cases.load("hk_norms")
     pot, prop = cases.oracle_potential(g), cases.oracle_propagator(g)
     assert abs(norm_oracle.norm(prop) - float(ref[f"{tag}_norm_0"])) < 1e-12
+    assert cases.rel_err(norm_oracle.wavefunction(prop, ref[f"{tag}_xgrid"]), ref[f"{tag}_psi_0"]) < 1e-11
     for _ in range(int(ref[f"{tag}_nsteps"])):
         prop.step(pot, float(g["dt"]))
     n = int(ref[f"{tag}_nsteps"])
     assert cases.rel_err(norm_oracle.coefficients(prop).numpy(), ref[f"{tag}_coeff_{n}"]) < 1e-11
     assert abs(norm_oracle.norm(prop) - float(ref[f"{tag}_norm_{n}"])) < 1e-10
+    assert cases.rel_err(norm_oracle.wavefunction(prop, ref[f"{tag}_xgrid"]), ref[f"{tag}_psi_{n}"]) < 1e-10

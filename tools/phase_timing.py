@@ -16,7 +16,8 @@ from semiclassical_amd._lib import lib, check, ptr  # noqa: E402
 
 torch.set_default_dtype(torch.float64)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-omega, chi, nac, q0, dt = bench.as60_model()
+DIM = int(os.environ.get("DIM", "60"))
+omega, chi, nac, q0, dt = bench.as60_model(DIM)
 G = torch.diag(omega)
 pot = P.MorsePotential(omega, chi.clone(), nac)
 prop = PR.HermanKlukPropagator(G, G, device="cuda")
@@ -38,7 +39,7 @@ def timed(fn, reps=5):
 desc = prop._potential_descriptor(pot)
 full = lambda: check(lib.sc_hk_step(desc, prop._state, prop._hk, dt, 0, ptr(prop._epart), prop._stream()))
 pref = lambda: check(lib.sc_hk_step(desc, prop._state, prop._hk, dt, 1, None, prop._stream()))
-ab = bench.algorithmic_bytes_per_traj_step(60) * n
+ab = bench.algorithmic_bytes_per_traj_step(DIM) * n
 for occ in os.environ.get("OCC_LIST", "2").split(","):
     os.environ["SC_SD_OCC"] = occ
     t_full = timed(full)
@@ -47,5 +48,5 @@ for occ in os.environ.get("OCC_LIST", "2").split(","):
     t_nolu = timed(full)
     t_load = timed(pref)
     del os.environ["SC_DEBUG_SKIP_LU"]
-    print(f"n={n} occ={occ}: full step {t_full:.3f} ms ({ab / t_full / 1e6:.0f} GB/s algorithmic) | without elimination "
+    print(f"D={DIM} n={n} occ={occ}: full step {t_full:.3f} ms ({ab / t_full / 1e6:.0f} GB/s algorithmic) | without elimination "
           f"{t_nolu:.3f} ms | prefactor only (load+mat+LU) {t_pref:.3f} ms | load+mat only {t_load:.3f} ms", flush=True)
