@@ -215,6 +215,14 @@ int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const sc_dense_scr
 int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
                        double dt, int32_t mode, void *stream);
 
+/* Structure-exploiting HK step ("separable shortcut"): same contract as sc_hk_step for a
+ * separable potential (SC_POT_MORSE / _HARMONIC_SEP / _EPS_MORSE), diagonal width matrices (hk->diag) and monodromy
+ * blocks that are diagonal, held as mono_diag[n][4][D] (diagonals of Mqq, Mqp, Mpq, Mpp) instead of st->mono, which
+ * is NOT touched.  Replaces the same reference code as sc_hk_step (propagators.py:86-119, 313-383, 951-1052) for this
+ * special case; opt-in on the host, reported separately from the dense-state kernel. */
+int sc_hk_step_diag(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, double *mono_diag,
+                    double dt, int32_t mode, double *energy_partials, void *stream);
+
 /* O(n^2) pairwise sum  sum_ij wb_i wk_j exp(rs_i + rs_j + X1_i.Y1_j + i (ib_i + ik_j + X2_i.Y2_j))  behind
  * HermanKlukPropagator.norm() (propagators.py:734-782): X1/Y1 [n][K1], X2/Y2 [n][K2] real, rs/ib/ik [n] real,
  * wb/wk [n] complex; partials[sc_pair_sum_tiles(n)][4] (re, im, 0, 0) for sc_reduce_slot. */

@@ -95,6 +95,8 @@ SIGNATURES = {
     "sc_pair_sum_tiles": (C.c_int64, [C.c_int64]),
     "sc_pair_sum": (C.c_int, [c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p,
                               c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, c_double_p, C.c_void_p]),
+    "sc_hk_step_diag": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), c_double_p, C.c_double, C.c_int32,
+                                  c_double_p, C.c_void_p]),
     "sc_grid_sum": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32, c_double_p,
                               c_double_p, C.c_int32, C.c_double, c_double_p, C.c_void_p]),
     "sc_reduce_slot": (C.c_int, [c_double_p, C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p,

@@ -50,7 +50,12 @@ def _resolve_device(device):
 class HermanKlukPropagator(object):
     """Herman-Kluk frozen-Gaussian propagator (reference propagators.py:407-1066)."""
 
-    def __init__(self, Gamma_i, Gamma_t, device='cuda'):
+    def __init__(self, Gamma_i, Gamma_t, device='cuda', exploit_separability=False):
+        """``exploit_separability`` (not in the reference): opt in to the O(D) diagonal-state kernel whenever the
+        potential is separable, the width matrices are diagonal and the monodromy matrices are still the diagonal
+        ones ``initial_conditions`` created -- the dense blocks the reference carries are then never formed on the
+        device unless ``y`` / ``monodromy_matrices()`` ask for them ("separable shortcut")."""
+        self.exploit_separability = bool(exploit_separability)
         Gamma_i, Gamma_t = hostmath.as_f64(Gamma_i), hostmath.as_f64(Gamma_t)
         assert hostmath.is_symmetric_non_negative(Gamma_i), "Gamma_i has to be symmetric and positive semi-definite."
         assert hostmath.is_symmetric_non_negative(Gamma_t), "Gamma_t has to be symmetric and positive semi-definite."
@@ -130,6 +135,11 @@ class HermanKlukPropagator(object):
         self._corr_step, self._corr_has_nac = -1, False
         self._nac, self._nac_key = None, None
         self._dense = None
+        # diagonals of the monodromy blocks for the separable shortcut; _mono is stale while they are ahead of it
+        self._mdiag = torch.zeros((n, 4, d), dtype=F64, device=dev)
+        self._mdiag[:, 0] = 1.0
+        self._mdiag[:, 3] = 1.0
+        self._mono_is_diag, self._mono_stale = True, False
 
         self._prepare()
         self.t = 0.0
@@ -189,10 +199,16 @@ class HermanKlukPropagator(object):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if hasattr(potential, "_gdml_model"):
+            self._sync_dense_mono(leave_diagonal=True)
             nblocks = self._launch_dense_step(potential, dt, s)
         else:
             desc = self._potential_descriptor(potential)
-            check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
+            if self._shortcut_applies(desc):
+                check(lib.sc_hk_step_diag(desc, self._state, self._hk, ptr(self._mdiag), dt, 0, ptr(self._epart), s))
+                self._mono_stale = True
+            else:
+                self._sync_dense_mono(leave_diagonal=True)
+                check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
             nblocks = self._gstep
         if timed:
             e1.record()
@@ -201,6 +217,19 @@ class HermanKlukPropagator(object):
         self._nsteps += 1
         self._remember_nac(potential)
         self._after_prefactor(track=1)
+
+    def _shortcut_applies(self, desc):
+        return (self.exploit_separability and self._mono_is_diag and bool(self._pre.diag)
+                and desc.kind in (_lib.SC_POT_MORSE, _lib.SC_POT_HARMONIC_SEP, _lib.SC_POT_EPS_MORSE))
+
+    def _sync_dense_mono(self, leave_diagonal=False):
+        """bring the dense monodromy blocks up to date with the diagonals the shortcut kernel advanced"""
+        if self._mono_stale:
+            self._mono.zero_()
+            torch.diagonal(self._mono, dim1=2, dim2=3).copy_(self._mdiag)
+            self._mono_stale = False
+        if leave_diagonal:
+            self._mono_is_diag = False          # a dense kernel takes over: the diagonals are no longer maintained
 
     def _launch_dense_step(self, potential, dt, s):
         """unfused RK4 step for a dense, position-dependent Hessian: four stage kernels + the monodromy kernel"""
@@ -344,6 +373,7 @@ class HermanKlukPropagator(object):
         """state in the reference's layout: rows (q, p, Mqq, Mqp, Mpq, Mpp, S), trajectories fastest"""
         d, n = self.dim, self.ntraj
         out = torch.empty((2 * d + 4 * d * d + 1, n), dtype=F64, device=self.device)
+        self._sync_dense_mono()
         check(lib.sc_state_to_reference(self._state, ptr(out), self._stream()))
         return out
 
@@ -355,6 +385,12 @@ class HermanKlukPropagator(object):
         check(lib.sc_state_from_reference(ptr(value), self._state, self._stream()))
         torch.cuda.current_stream(self.device).synchronize()     # `value` may be a temporary
         self._corr_step = -1
+        # the new monodromy blocks may or may not be diagonal: keep the shortcut only if they are
+        diag = torch.diagonal(self._mono, dim1=2, dim2=3)
+        self._mono_stale = False
+        self._mono_is_diag = bool(torch.count_nonzero(self._mono) == torch.count_nonzero(diag))
+        if self._mono_is_diag:
+            self._mdiag.copy_(diag)
 
     @property
     def c(self):
@@ -373,6 +409,7 @@ class HermanKlukPropagator(object):
 
     def monodromy_matrices(self):
         # (n, D, D) -> (D, D, n) views
+        self._sync_dense_mono()
         return tuple(self._mono[:, k].permute(1, 2, 0) for k in range(4))
 
     def semiclassical_prefactor(self):
@@ -466,7 +503,7 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
     """
 
     def __init__(self, Gamma_i, Gamma_t, alpha, beta, device='cuda'):
-        super().__init__(Gamma_i, Gamma_t, device=device)
+        super().__init__(Gamma_i, Gamma_t, device=device)      # the Filinov matrix needs the dense monodromy blocks
         self.alpha = torch.tensor(float(alpha))
         self.beta = torch.tensor(float(beta))
 

@@ -34,13 +34,13 @@ def engine_potential(g):
     raise ValueError(kind)
 
 
-def engine_propagator(g, device="cuda"):
+def engine_propagator(g, device="cuda", **kwargs):
     from semiclassical_amd import propagators as PR
     Gi, Gt = cases.T(g["Gamma_i"]), cases.T(g["Gamma_t"])
     if "alpha" in g:
         prop = PR.WaltonManolopoulosPropagator(Gi, Gt, float(g["alpha"]), float(g["beta"]), device=device)
     else:
-        prop = PR.HermanKlukPropagator(Gi, Gt, device=device)
+        prop = PR.HermanKlukPropagator(Gi, Gt, device=device, **kwargs)
     prop.set_initial_conditions(cases.T(g["q0"]), cases.T(g["p0"]), cases.T(g["Gamma_0"]),
                                 cases.T(g["zi"]), cases.T(g["probi"]))
     return prop
