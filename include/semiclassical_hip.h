@@ -66,8 +66,9 @@ typedef struct sc_state {
     double *c2;
     double *sgn;
     double *work;           /* [n][4][D] scratch of the separable fast path: RK4 propagators of the monodromy rows */
-    int32_t *flags;         /* [n], zero-initialised scratch: trajectories whose determinant the fast
-                               path hands to the fully pivoted elimination (may be NULL) */
+    int32_t *flags;         /* [n + 1], zero-initialised scratch: flags[i] != 0 marks a trajectory whose determinant
+                               the fast path hands to the fully pivoted elimination, flags[n] counts them for the
+                               current step (may be NULL) */
 } sc_state;
 
 /* constants of the HK prefactor, reference propagators.py:951-1004.

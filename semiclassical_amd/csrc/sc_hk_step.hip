@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
     // mode & 0xff: 0 = step + prefactor, 1 = prefactor only + tracker initialisation
     // mode & 0x200: fix-up pass -- only trajectories flagged by the fast path, prefactor + tracking only
     const bool fixup = (A.mode & 0x200) != 0;
+    if (fixup && A.st.flags[A.st.n] == 0) return;          // flags[n] counts the trajectories flagged in this step
     const bool do_step = (A.mode & 0xff) == 0 && !fixup;
     const bool init_track = (A.mode & 0xff) == 1;
     const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
@@ -256,6 +257,8 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
         // measured slower on MI355X (12.2 ms vs 9.5 ms per step at D=60, n=1e5), kept as the reference variant
         const char *which = getenv("SC_FAST_KERNEL");
         if (which && which[0] == 'r') return sc_launch_step_rw(a, (hipStream_t)stream);
+        if (st->flags && hipMemsetAsync(st->flags + st->n, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
+            return sc_check_launch("sc_hk_step (flag counter)");
         const int rc = sc_launch_step_sd(a, (hipStream_t)stream);
         if (rc != SC_OK || !st->flags || (dbg & 0x100)) return rc;
         mode |= 0x200;      // fully pivoted fix-up of the trajectories the fast path flagged (normally none)

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         __syncthreads();
         if (tid == 0 && weak && A.st.flags && !(A.mode & 0x100)) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
+            atomicAdd(&A.st.flags[A.st.n], 1);   // lets the fix-up launch return at once when nothing was flagged
         } else if (tid == 0) {
             if (singular) {
                 det = c_make(0.0, 0.0);

@@ -118,7 +118,7 @@ class HermanKlukPropagator(object):
         self._mono[:, 3] = eye
         self._c2 = torch.ones(n, dtype=C128, device=dev)
         self._sgn = torch.ones(n, dtype=F64, device=dev)
-        self._flags = torch.zeros(n, dtype=torch.int32, device=dev)
+        self._flags = torch.zeros(n + 1, dtype=torch.int32, device=dev)     # [n] = flagged count
         self._work = torch.zeros((n, 4, d), dtype=F64, device=dev)
         self._state = sc_state(n=n, dim=d, qp=ptr(self._qp), act=ptr(self._act), mono=ptr(self._mono),
                                c2=ptr(self._c2), sgn=ptr(self._sgn), work=ptr(self._work), flags=ptr(self._flags))
