@@ -1,0 +1,241 @@
+// RK4 of the four monodromy blocks under DENSE, stage-dependent Hessians on the matrix cores, and the HK prefactor of
+// the result -- the "batched D x D monodromy GEMM" of the dense-Hessian configurations (sGDML, SURVEY.md rows B + C4).
+//
+// With X = [Mqq | Mqp] and Y = [Mpq | Mpp] (D x 2D each) the equations of motion (reference propagators.py:352-362)
+// are X' = W Y, Y' = -H X with W = diag(1/m): four GEMMs H_s X_s (D x D times D x 2D, 16 D^3 flop) per RK4 step
+// (propagators.py:86-119).  Kernel `dense_mono_mfma_kernel<NT>` (NT = ceil(D/16) <= 4):
+//   * one workgroup of 2 NT wavefronts per trajectory; a wavefront owns one 16-column tile of X and of Y for ALL rows
+//     and keeps X0, Y0, the RK4 sums and the stage matrices in registers, in the accumulator layout of
+//     v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 reg within a 16 x 16 tile);
+//   * that layout IS the B-operand layout of the next product: register r of row tile t holds rows 16t + 4r .. + 3
+//     across the four 16-lane groups, i.e. the k-slice 4(4t + r) -- the stage matrix never moves between products;
+//   * the A operand (H_s, shared by all wavefronts) is staged in LDS, double buffered so that the next stage's
+//     Hessian streams in behind the current stage's 16 NT^2 MFMAs; rows padded to 80 doubles make the one-double-
+//     per-lane reads (4 rows x 16 columns) conflict free.  The LDS image is used as A[i][k] = Hs[k][i]: the stage
+//     Hessians are symmetric (the sGDML kernel writes both triangles from one value), so no transpose is needed.
+// FP64 MFMA peak on MI355X is 78.6 TFLOP/s = 64 cycles per 16x16x4 instruction per SIMD; at D = 64 the four products
+// are 2048 MFMAs = 32.8k cycles per trajectory on one CU.
+// `dense_prefactor_kernel` then forms the (projected) prefactor matrix from the new blocks and takes the determinant
+// by pivoted LU in LDS, followed by the branch tracker (propagators.py:951-1052).
+#include "sc_common.h"
+#include "sc_prefactor.h"
+
+namespace {
+
+struct MonoArgs {
+    sc_state st;
+    sc_hk_consts hk;
+    const double *inv_mass;
+    const double *hess;         // [n][4][D][D] stage Hessians, or [D][D] when hess_stride == 0 (constant Hessian)
+    int64_t hess_stride;        // doubles between the Hessian blocks of consecutive trajectories (4 D D or 0)
+    int64_t stage_stride;       // doubles between consecutive stages (D D or 0)
+    double dt;
+    int mode;                   // 0: after a step, 1: tracker initialisation (prefactor kernel only)
+};
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define HS 80                   // LDS row stride of the Hessian image (doubles)
+
+template <int NT, int KT>          // NT = ceil(D/16) row tiles, KT = ceil(D/4) k-slices of four rows (compile time: the
+                                  // product loop must be branch free or the accumulators bounce between register files)
+__global__ __launch_bounds__(128 * NT, 1) void dense_mono_mfma_kernel(MonoArgs A) {
+    extern __shared__ double2 smem2[];           // Hessian images [2][16 NT][HS], 1/m [64], X0/Y0 [waves][2][4 NT][64]
+    constexpr int HB = 16 * NT * HS;             // doubles per image
+    double *Hs0 = (double *)smem2, *wm = Hs0 + 2 * HB;
+    // the step's initial matrices are only needed to form the stage inputs: parked in LDS (own slot per lane:
+    // conflict free) they free registers for the products.  At NT = 4 only Y0 fits beside the Hessian images.
+    constexpr bool PARK_X = NT < 4;
+    constexpr int PARKED = PARK_X ? 2 : 1;
+    double *Y0 = wm + 64 + (size_t)(threadIdx.x >> 6) * (PARKED * 4 * NT * 64) + (threadIdx.x & 63), *X0 = Y0 + 4 * NT * 64;
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x, nth = 128 * NT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int pair = wave / NT, jt = wave % NT;          // pair 0: (Mqq, Mpq), pair 1: (Mqp, Mpp); column tile jt
+    const int col = 16 * jt + (lane & 15), rg = lane >> 4;
+    const bool colok = col < D;
+    const unsigned toff = (unsigned)(rg * D + col);
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    constexpr int HPT = 2 * NT;                          // Hessian elements staged per thread: (16 NT)^2 / (128 NT)
+
+    if (tid < 64) wm[tid] = tid < D ? A.inv_mass[tid] : 0.0;
+    for (int e = tid; e < 2 * HB; e += nth) Hs0[e] = 0.0;                   // padding rows / columns stay zero
+    __syncthreads();
+
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        double *Mx = A.st.mono + tr * 4 * (int64_t)DD + (int64_t)pair * DD;
+        double *My = Mx + 2 * (int64_t)DD;
+        const double *Hg = A.hess + tr * A.hess_stride;
+        // stage-1 Hessian -> LDS buffer 0 (row k of the image = row k of H, see the header)
+        __syncthreads();
+        for (int e = tid; e < DD; e += nth) Hs0[(e / D) * HS + (e % D)] = Hg[e];
+        // this wavefront's column tile of X and Y
+        double SX[NT][4], SY[NT][4], Xs[NT][4], Ys[NT][4], X0r[PARK_X ? 1 : NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + rg + 4 * r;
+                const bool ok = colok && row < D;
+                // wave-uniform row base + one per-thread 32-bit offset (keeps hipcc from hoisting 64-bit offsets)
+                Xs[t][r] = ok ? (Mx + (16 * t + 4 * r) * D)[toff] : 0.0;
+                Ys[t][r] = ok ? (My + (16 * t + 4 * r) * D)[toff] : 0.0;
+                if (PARK_X) X0[(4 * t + r) * 64] = Xs[t][r]; else X0r[PARK_X ? 0 : t][r] = Xs[t][r];
+                Y0[(4 * t + r) * 64] = Ys[t][r];
+            }
+#pragma unroll 1
+        for (int st = 0; st < 4; ++st) {
+            __syncthreads();                             // Hessian image of this stage complete
+            const double *Hb = Hs0 + (st & 1) * HB;
+            // next stage's Hessian: global -> registers now, registers -> LDS after the products
+            double hn[HPT];
+            const double *Hn = Hg + (st + 1) * A.stage_stride;
+            if (st < 3) {
+#pragma unroll
+                for (int i = 0; i < HPT; ++i) {
+                    const int e = tid + i * nth;
+                    hn[i] = e < DD ? Hn[e] : 0.0;
+                }
+            }
+            d4 acc[NT];
+#pragma unroll
+            for (int I = 0; I < NT; ++I) acc[I] = (d4){0.0, 0.0, 0.0, 0.0};
+            // A operands one k-slice ahead of the products; the scheduling barriers keep hipcc from hoisting all
+            // 4 NT^2 LDS reads of the stage to the top (that spills hundreds of bytes per lane)
+            const double *arow = Hb + rg * HS + (lane & 15);
+            double a_cur[NT], a_nxt[NT];
+#pragma unroll
+            for (int I = 0; I < NT; ++I) a_cur[I] = arow[16 * I];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt + 1 < KT) {
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) a_nxt[I] = arow[4 * (kt + 1) * HS + 16 * I];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double b = Xs[kt >> 2][kt & 3];
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[I], b, acc[I], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int I = 0; I < NT; ++I) a_cur[I] = a_nxt[I];
+            }
+            if (st < 3) {
+                double *Hw = Hs0 + ((st + 1) & 1) * HB;
+#pragma unroll
+                for (int i = 0; i < HPT; ++i) {
+                    const int e = tid + i * nth;
+                    if (e < DD) Hw[(e / D) * HS + (e % D)] = hn[i];
+                }
+            }
+            const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                __builtin_amdgcn_sched_barrier(0);       // one row tile of LDS operands (1/m, X0, Y0) at a time
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double kx = wm[16 * t + rg + 4 * r] * Ys[t][r], ky = -acc[t][r];
+                    if (st == 0) { SX[t][r] = kx; SY[t][r] = ky; }
+                    else { SX[t][r] = fma(wgt, kx, SX[t][r]); SY[t][r] = fma(wgt, ky, SY[t][r]); }
+                    Xs[t][r] = fma(c, kx, PARK_X ? X0[(4 * t + r) * 64] : X0r[PARK_X ? 0 : t][r]);
+                    Ys[t][r] = fma(c, ky, Y0[(4 * t + r) * 64]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + rg + 4 * r;
+                if (colok && row < D) {
+                    (Mx + (16 * t + 4 * r) * D)[toff] = fma(h6, SX[t][r], PARK_X ? X0[(4 * t + r) * 64] : X0r[PARK_X ? 0 : t][r]);
+                    (My + (16 * t + 4 * r) * D)[toff] = fma(h6, SY[t][r], Y0[(4 * t + r) * 64]);
+                }
+            }
+    }
+}
+
+// prefactor matrix, determinant and branch tracker from the monodromy blocks in global memory
+__global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
+    extern __shared__ double2 smem2[];
+    __shared__ int ipiv;
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x, nth = blockDim.x, dp = A.hk.dprime;
+    cplx *mat = (cplx *)smem2, *X = mat + (size_t)dp * dp;
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        const double *M = A.st.mono + tr * 4 * (int64_t)DD;
+        __syncthreads();
+        if (A.hk.diag) {
+            for (int e = tid; e < DD; e += nth) {
+                const int a = e / D, b = e - a * D;
+                const double sta = A.hk.st[a], sib = A.hk.si[b];
+                mat[e] = c_make(0.5 * (sta / sib * M[e] + sib / sta * M[3 * DD + e]),
+                                0.5 * (-SC_HBAR * sta * sib * M[DD + e] + M[2 * DD + e] / (SC_HBAR * sta * sib)));
+            }
+            __syncthreads();
+        } else {
+            general_prefactor_matrix(A.hk, M, M + DD, M + 2 * DD, M + 3 * DD, D, X, mat);
+        }
+        const cplx det = lds_lu_det(mat, dp, &ipiv);
+        if (tid == 0) {
+            cplx *c2 = (cplx *)A.st.c2;
+            if (A.mode == 0) {
+                const cplx prev = c2[tr];
+                if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
+            } else {
+                A.st.sgn[tr] = 1.0;
+            }
+            c2[tr] = det;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
+                                  double dt, int32_t mode, void *stream) {
+    if (!st || !hk || (mode == 0 && (!inv_mass || !hess)))
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: null argument");
+    const int D = st->dim;
+    if (D < 1 || D > 64) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d outside 1..64", D);
+    if (hk->dim != D || hk->dprime < 1 || hk->dprime > D)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: bad prefactor constants");
+    if (st->n <= 0) return SC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    MonoArgs a{*st, *hk, inv_mass, hess, 4 * (int64_t)D * D, (int64_t)D * D, dt, mode};
+    if (mode == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int nt = (D + 15) / 16;
+        const size_t rk4_lds = ((size_t)2 * 16 * nt * HS + 64 + (size_t)2 * nt * (nt < 4 ? 2 : 1) * 4 * nt * 64) * sizeof(double);
+#define SC_LAUNCH_MONO(NT_, KT_, WGS_)                                                                              \
+        do {                                                                                                        \
+            if (hipFuncSetAttribute((const void *)dense_mono_mfma_kernel<NT_, KT_>,                                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk4_lds) != hipSuccess)        \
+                return sc_check_launch("sc_dense_mono_step (LDS attribute)");                                       \
+            const int64_t g_ = (int64_t)cus * (WGS_);                                                               \
+            hipLaunchKernelGGL((dense_mono_mfma_kernel<NT_, KT_>), dim3((unsigned)(st->n < g_ ? st->n : g_)),       \
+                               dim3(128 * NT_), rk4_lds, s, a);                                                     \
+        } while (0)
+#define SC_MONO_CASES(NT_, WGS_)                                                                                    \
+        case 4 * NT_ - 3: SC_LAUNCH_MONO(NT_, 4 * NT_ - 3, WGS_); break;                                            \
+        case 4 * NT_ - 2: SC_LAUNCH_MONO(NT_, 4 * NT_ - 2, WGS_); break;                                            \
+        case 4 * NT_ - 1: SC_LAUNCH_MONO(NT_, 4 * NT_ - 1, WGS_); break;                                            \
+        case 4 * NT_: SC_LAUNCH_MONO(NT_, 4 * NT_, WGS_); break;
+        switch ((D + 3) / 4) {
+            SC_MONO_CASES(1, 8)
+            SC_MONO_CASES(2, 4)
+            SC_MONO_CASES(3, 1)
+            SC_MONO_CASES(4, 1)
+        }
+#undef SC_MONO_CASES
+#undef SC_LAUNCH_MONO
+        const int rc = sc_check_launch("sc_dense_mono_step (RK4)");
+        if (rc) return rc;
+    }
+    const size_t lds = ((size_t)hk->dprime * hk->dprime + (hk->diag ? 0 : (size_t)D * hk->dprime)) * 16 + 32;
+    if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: needs %zu B of LDS", lds);
+    if (hipFuncSetAttribute((const void *)dense_prefactor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return sc_check_launch("sc_dense_mono_step (LDS attribute)");
+    hipLaunchKernelGGL(dense_prefactor_kernel, dim3(sc_dense_grid(st->n)), dim3(256), lds, s, a);
+    return sc_check_launch("sc_dense_mono_step");
+}

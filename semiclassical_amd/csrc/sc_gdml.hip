@@ -286,120 +286,6 @@ __global__ __launch_bounds__(256) void gdml_stage_kernel(StageArgs A) {
     if (tid == 0 && A.epart && s == 3) A.epart[blockIdx.x] = esum;
 }
 
-// ------------------------------------------------------------------ RK4 of the monodromy blocks with 4 dense Hessians
-struct MonoArgs {
-    sc_state st;
-    sc_hk_consts hk;
-    const double *inv_mass;
-    const double *hess;     // [n][4][D][D]
-    double dt;
-    int mode;               // 0: step + prefactor, 1: prefactor only + tracker initialisation
-};
-
-#define MONO_NS 32          // register slots per thread: rows a = grp + G s, s < MONO_NS  (D <= 64)
-
-__global__ __launch_bounds__(256, 1) void dense_mono_kernel(MonoArgs A) {
-    extern __shared__ double2 smem2[];
-    __shared__ int ipiv;
-    double *smem = (double *)smem2;
-    const int D = A.st.dim, DD = D * D, W = 2 * D, tid = threadIdx.x, nth = blockDim.x;
-    const int dp = A.hk.dprime;
-    const bool diag = A.hk.diag != 0, do_step = A.mode == 0;
-    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
-    // column-owner mapping: thread -> (column col of the D x 2D matrices, row group grp)
-    const int G = nth / W, col = tid % W, grp = tid / W;
-    const bool active = grp < G;
-    const int plane_q = col < D ? 0 : 1, plane_p = col < D ? 2 : 3, cc = col < D ? col : col - D;
-    // LDS: RK4 phase {Q (D x 2D), H (D x D)} ; prefactor phase {mat (dp x dp complex), X (D x dp complex)}
-    double *Q = smem, *Hs = smem + (size_t)D * W;
-    cplx *mat = (cplx *)smem, *X = mat + (size_t)dp * dp;
-
-    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
-        double *M = A.st.mono + tr * 4 * (int64_t)DD;
-        __syncthreads();
-        if (do_step) {
-            double mq[MONO_NS], mp[MONO_NS], aq[MONO_NS], ap[MONO_NS], ps[MONO_NS];
-#pragma unroll
-            for (int s = 0; s < MONO_NS; ++s) {
-                const int a = grp + G * s;
-                const bool ok = active && a < D;
-                mq[s] = ok ? M[plane_q * DD + a * D + cc] : 0.0;
-                mp[s] = ok ? M[plane_p * DD + a * D + cc] : 0.0;
-                ps[s] = mp[s]; aq[s] = 0.0; ap[s] = 0.0;
-                if (ok) Q[a * W + col] = mq[s];
-            }
-            for (int st = 0; st < 4; ++st) {
-                const double *Hg = A.hess + ((size_t)tr * 4 + st) * DD;
-                for (int e = tid; e < DD; e += nth) Hs[e] = Hg[e];
-                __syncthreads();
-                double kp[MONO_NS];
-#pragma unroll
-                for (int s = 0; s < MONO_NS; ++s) kp[s] = 0.0;
-                if (active) {
-                    for (int g = 0; g < D; ++g) {
-                        const double qv = Q[g * W + col];
-#pragma unroll
-                        for (int s = 0; s < MONO_NS; ++s) {
-                            const int a = grp + G * s;
-                            if (a < D) kp[s] = fma(-Hs[a * D + g], qv, kp[s]);
-                        }
-                    }
-                }
-                __syncthreads();
-                const double w = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
-#pragma unroll
-                for (int s = 0; s < MONO_NS; ++s) {
-                    const int a = grp + G * s;
-                    if (active && a < D) {
-                        const double kq = ps[s] * A.inv_mass[a];
-                        aq[s] += w * kq; ap[s] += w * kp[s];
-                        if (st < 3) { Q[a * W + col] = mq[s] + c * kq; ps[s] = mp[s] + c * kp[s]; }
-                    }
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int s = 0; s < MONO_NS; ++s) {
-                const int a = grp + G * s;
-                if (active && a < D) {
-                    M[plane_q * DD + a * D + cc] = mq[s] + h6 * aq[s];
-                    M[plane_p * DD + a * D + cc] = mp[s] + h6 * ap[s];
-                }
-            }
-            __syncthreads();
-        }
-        // ---- prefactor from the (new) monodromy blocks in global memory
-        if (diag) {
-            for (int e = tid; e < DD; e += nth) {
-                const int a = e / D, b = e - a * D;
-                const double sta = A.hk.st[a], sib = A.hk.si[b];
-                mat[e] = c_make(0.5 * (sta / sib * M[e] + sib / sta * M[3 * DD + e]),
-                                0.5 * (-SC_HBAR * sta * sib * M[DD + e] + M[2 * DD + e] / (SC_HBAR * sta * sib)));
-            }
-            __syncthreads();
-        } else {
-            general_prefactor_matrix(A.hk, M, M + DD, M + 2 * DD, M + 3 * DD, D, X, mat);
-        }
-        const cplx det = lds_lu_det(mat, dp, &ipiv);
-        if (tid == 0) {
-            cplx *c2 = (cplx *)A.st.c2;
-            if (do_step) {
-                const cplx prev = c2[tr];
-                if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
-            } else {
-                A.st.sgn[tr] = 1.0;
-            }
-            c2[tr] = det;
-        }
-    }
-}
-
-size_t mono_lds_bytes(int D, int dp, int diag) {
-    const size_t rk4 = ((size_t)D * 2 * D + (size_t)D * D) * 8;
-    const size_t pre = ((size_t)dp * dp + (diag ? 0 : (size_t)D * dp)) * 16;
-    return (rk4 > pre ? rk4 : pre) + 32;
-}
-
 int check_model(const sc_gdml_model *g, const char *who) {
     if (!g || !g->xs_train || !g->jx_alphas || !g->pair_k || !g->pair_l)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null model field", who);
@@ -445,23 +331,4 @@ extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const s
         return sc_check_launch("sc_gdml_stage (LDS attribute)");
     hipLaunchKernelGGL(gdml_stage_kernel, dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a);
     return sc_check_launch("sc_gdml_stage");
-}
-
-extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
-                                  double dt, int32_t mode, void *stream) {
-    if (!st || !hk || (mode == 0 && (!inv_mass || !hess)))
-        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: null argument");
-    const int D = st->dim;
-    if (D > 64 || 2 * D > 256) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d > 64", D);
-    if (hk->dim != D || hk->dprime < 1 || hk->dprime > D) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: bad prefactor constants");
-    const int G = 256 / (2 * D);
-    if ((D + G - 1) / G > MONO_NS) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d needs more register slots", D);
-    if (st->n <= 0) return SC_OK;
-    const size_t lds = mono_lds_bytes(D, hk->dprime, hk->diag);
-    if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: needs %zu B of LDS", lds);
-    MonoArgs a{*st, *hk, inv_mass, hess, dt, mode};
-    if (hipFuncSetAttribute((const void *)dense_mono_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return sc_check_launch("sc_dense_mono_step (LDS attribute)");
-    hipLaunchKernelGGL(dense_mono_kernel, dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a);
-    return sc_check_launch("sc_dense_mono_step");
 }
