@@ -10,7 +10,7 @@ assertion.  The time loop itself is ``propagator.run`` (no host synchronisation 
     python -m semiclassical_amd.driver rates input.json
 
 Not carried over: extxyz export, ``calc_norm_every``, plotting (outside the hot path).
-Potential type "gdml" is not available in this round.
+Potential types: "harmonic", "anharmonic AS", "gdml" (cli.py:178-303).
 """
 import argparse
 import json
@@ -59,7 +59,20 @@ def _build_problem(task):
         potential = potentials.MorsePotential(omega, chi, nac)
         return potential, dQ, 0.0 * dQ, torch.diag(omega), torch.sum(hbar / 2.0 * omega).item(), np.nan
     if p['type'] == "gdml":
-        raise NotImplementedError("the sGDML potential is not available on the HIP engine in this round")
+        from .gdml import MolecularGDMLPotential
+        model_pot = np.load(p['ground'], allow_pickle=True)
+        with open(p['coupling']) as f:
+            nacs_fchk = readers.FormattedCheckpointFile(f)
+        with open(p['excited']) as f:
+            excited_fchk = readers.FormattedCheckpointFile(f)
+        potential = MolecularGDMLPotential(model_pot, nacs_fchk)
+        x0, Gamma_0, en_zpt = excited_fchk.vibrational_groundstate()
+        q0 = torch.from_numpy(x0)
+        p0 = torch.zeros_like(q0)
+        Gamma_0 = torch.from_numpy(Gamma_0)
+        potential.minimize(q0)          # raises the reference's RuntimeError when Newton + Armijo does not converge
+        gap = excited_fchk.total_energy() - potential.total_energy()
+        return potential, q0, p0, Gamma_0, en_zpt, gap
     raise ConfigurationError(f"Unknown potential type in {task['potential']}")
 
 
