@@ -120,6 +120,14 @@ typedef struct sc_wm_consts {
     const double *n1, *s_n1, *w_n1;
     double inv_scale_a, inv_two_pi, pre, p0n1, n2;
     double *detA, *detM, *sgnA, *sgnM;
+    /* optional per-trajectory export behind WaltonManolopoulosPropagator.coefficients() / wavefunction() / norm()
+     * (propagators.py:1391-1575); each may be NULL:
+     *   coef_out [n] complex   v_n of eqn (75) without the x-dependent part, :1408-1432, with
+     *                          pre_coef = detG0^1/4 detGt^1/4 detGi^1/4 / sqrt(detGi0)
+     *   cqq_out  [n][D][D] complex   C_QQ of eqn (70)
+     *   dvec_out [n][D] complex      C_qQ^T (q0 - q) + i/hbar PI_Q, :1513 */
+    double pre_coef;
+    double *coef_out, *cqq_out, *dvec_out;
 } sc_wm_consts;
 
 /* sGDML force field, reference semiclassical/gdml_predictor.py:57-85 (constructor) and :96-250 (forward).
@@ -237,6 +245,12 @@ int sc_pair_sum(const double *X1, const double *Y1, int32_t K1, const double *X2
  * LqT, PT [D][n] (trajectory index fastest), pq [n], v [n] complex, Lx, X [nx][D], phi [nx] complex. */
 int sc_grid_sum(const double *LqT, const double *PT, const double *pq, const double *v, int64_t n, int32_t D,
                 const double *Lx, const double *X, int32_t nx, double fac, double *phi, void *stream);
+
+/* Walton-Manolopoulos wavefunction on a spatial grid (propagators.py:1434-1482):
+ *   phi[k] = sum_n v_n exp(-1/2 dx^T CQQ_n dx + dvec_n . dx),  dx = x_k - Q_n
+ * with the per-trajectory export of sc_wm_correlate; qp [n][2D] (engine state), X [nx][D], phi [nx] complex. */
+int sc_wm_grid_sum(const double *qp, const double *coef, const double *cqq, const double *dvec, int64_t n, int32_t D,
+                   const double *X, int32_t nx, double *phi, void *stream);
 
 /* Energy-conservation guard on the device, reference propagators.py:385-398 (check_energy_conservation).
  * elog[4] = { <T+V>(t-dt), <T+V>(t), largest |change| seen so far, number of steps logged }.

@@ -44,3 +44,29 @@ def wavefunction(prop, x):
     dx = x.unsqueeze(1) - q.unsqueeze(2)                                   # (dim, ntraj, nx)
     expo = -0.5 * torch.einsum('inx,ij,jnx->nx', dx, Gt, dx) + 1j / hbar * torch.einsum('in,inx->nx', p, dx)
     return torch.sum(v.unsqueeze(1) * fac * torch.exp(expo), 0).numpy()
+
+
+def wm_coefficients(prop):
+    """Walton-Manolopoulos coefficients of eqn (75), x-independent part (reference propagators.py:1391-1432)"""
+    d, n = prop.dim, prop.ntraj
+    C, S = prop.semiclassical_prefactor(), prop.classical_action()
+    v = (prop.detG0 ** 0.25 * prop.detGt ** 0.25 * prop.detGi ** 0.25 / torch.sqrt(prop.detGi0) / (2 * np.pi) ** d
+         * C * torch.exp(1j / hbar * S) / torch.sqrt(prop.detA) * prop.tracker.signs("detA") * torch.exp(prop.eps))
+    q, p = prop.initial_positions_and_momenta()
+    dq = (prop.q0.unsqueeze(1) - q).type(torch.complex128)
+    v = v * torch.exp(-0.5 * torch.einsum('in,ijn,jn->n', dq, prop.Cqq, dq)
+                      - 1j / hbar * torch.einsum('in,in->n', prop.PIq, dq))
+    return v / (n * prop.probi)
+
+
+def wm_wavefunction(prop, x):
+    """WM wavefunction on the grid x (dim,nx) (reference propagators.py:1434-1482)"""
+    x = torch.as_tensor(x, dtype=torch.float64)
+    v = wm_coefficients(prop)
+    q, _ = prop.initial_positions_and_momenta()
+    Q, _ = prop.current_positions_and_momenta()
+    dq = (prop.q0.unsqueeze(1) - q).type(torch.complex128)
+    dx = (x.unsqueeze(1) - Q.unsqueeze(2)).type(torch.complex128)                      # (dim, ntraj, nx)
+    expo = (-0.5 * torch.einsum('inx,ijn,jnx->nx', dx, prop.CQQ, dx) + torch.einsum('in,ijn,jnx->nx', dq, prop.CqQ, dx)
+            + 1j / hbar * torch.einsum('in,inx->nx', prop.PIQ, dx))
+    return torch.sum(v.unsqueeze(1) * torch.exp(expo), 0).numpy()

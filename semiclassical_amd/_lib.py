@@ -50,7 +50,8 @@ class sc_wm_consts(C.Structure):
                 ("n1", c_double_p), ("s_n1", c_double_p), ("w_n1", c_double_p),
                 ("inv_scale_a", C.c_double), ("inv_two_pi", C.c_double), ("pre", C.c_double),
                 ("p0n1", C.c_double), ("n2", C.c_double),
-                ("detA", c_double_p), ("detM", c_double_p), ("sgnA", c_double_p), ("sgnM", c_double_p)]
+                ("detA", c_double_p), ("detM", c_double_p), ("sgnA", c_double_p), ("sgnM", c_double_p),
+                ("pre_coef", C.c_double), ("coef_out", c_double_p), ("cqq_out", c_double_p), ("dvec_out", c_double_p)]
 
 
 class sc_gdml_model(C.Structure):
@@ -85,6 +86,8 @@ SIGNATURES = {
     "sc_wm_grid": (C.c_int, [C.c_int64, C.c_int32]),
     "sc_wm_correlate": (C.c_int, [P(sc_state), P(sc_wm_consts), c_double_p, c_double_p, C.c_double, C.c_int32,
                                   C.c_int32, c_double_p, c_double_p, c_double_p, C.c_void_p]),
+    "sc_wm_grid_sum": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32, c_double_p,
+                                 C.c_int32, c_double_p, C.c_void_p]),
     "sc_gdml_eval": (C.c_int, [P(sc_gdml_model), c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p,
                                C.c_void_p]),
     "sc_dense_grid": (C.c_int, [C.c_int64]),

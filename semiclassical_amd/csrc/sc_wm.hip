@@ -244,6 +244,15 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             Gt[e] = c_sub(Gt[e], s);         // each thread only touches its own element of Gt
         }
         __syncthreads();
+        if (W.cqq_out) {
+            cplx *out = (cplx *)W.cqq_out + tr * (int64_t)DD;
+            for (int e = tid; e < DD; e += nth) out[e] = Gt[e];
+        }
+        if (W.dvec_out) {                        // C_qQ^T (q0 - q) + i/hbar PI_Q = u_dq + i/hbar (y + p0)
+            cplx *out = (cplx *)W.dvec_out + tr * (int64_t)D;
+            for (int a = tid; a < D; a += nth)
+                out[a] = c_make(cv[a].x - ihb * cv[4 * D + a].y, cv[a].y + ihb * (cv[4 * D + a].x + cp0[a]));
+        }
         // M'/(2 pi) = U^T (G0 + CQQ) U / (2 pi) ; identity on the right ; hat = U^T {5 vectors}
         for (int e = tid; e < dp * dp; e += nth) {
             const int i = e / dp, j = e - i * dp;
@@ -336,6 +345,12 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             const cplx cq = c_scale(c_mul(pre, c_exp(ex)), w);                      // (85) / (n P (2 pi hbar)^D)
             acc[0] += cq.x; acc[1] += cq.y;
             if (A.cq_out) ((cplx *)A.cq_out)[tr] = cq;
+            if (W.coef_out) {                   // eqn (75) without its x-dependent part, propagators.py:1408-1432
+                cplx v = c_mul(cpre, c_exp(c_make(0.0, A.st.act[tr] * ihb)));
+                v = c_mul(v, c_scale(c_inv(c_sqrt(detA)), sA));
+                v = c_mul(v, c_exp(c_make(eps - 0.5 * dqCdq, -ihb * piq_dq)));
+                ((cplx *)W.coef_out)[tr] = c_scale(v, W.pre_coef / (A.mc_norm * A.probi[tr]));
+            }
             if (A.has_nac) {
                 const cplx nacqQ = form(UN1, WN1);
                 const cplx PQ_n1 = c_add(c_make(W.p0n1, 0), form(WN1, Y));
@@ -368,7 +383,55 @@ size_t wm_lds_bytes(int D, int dp) {
 
 size_t wm_const_bytes(int D, int dp) { return ((size_t)D * dp + 5 * (size_t)D * D + 5 * (size_t)D) * 8; }
 
+// WM wavefunction on a grid: one workgroup per grid point, threads stride over the trajectories
+struct WmGridArgs {
+    const double *qp, *coef, *cqq, *dvec;
+    int64_t n;
+    int D, nx;
+    const double *X;
+    double *phi;
+};
+
+__global__ __launch_bounds__(256) void wm_grid_sum_kernel(WmGridArgs A) {
+    extern __shared__ double2 smem2[];
+    __shared__ double red[32];
+    double *xs = (double *)smem2;
+    const int tid = threadIdx.x, D = A.D, k = blockIdx.x;
+    for (int a = tid; a < D; a += 256) xs[a] = A.X[(size_t)k * D + a];
+    __syncthreads();
+    double acc[2] = {0.0, 0.0};
+    for (int64_t i = tid; i < A.n; i += 256) {
+        const double *Q = A.qp + i * 2 * D;
+        const cplx *C = (const cplx *)A.cqq + i * (int64_t)D * D, *d = (const cplx *)A.dvec + i * D;
+        cplx ex = c_make(0.0, 0.0);
+        for (int a = 0; a < D; ++a) {
+            const double dxa = xs[a] - Q[a];
+            cplx row = c_make(0.0, 0.0);
+            for (int b = 0; b < D; ++b) {
+                const double dxb = xs[b] - Q[b];
+                row.x = fma(C[a * D + b].x, dxb, row.x); row.y = fma(C[a * D + b].y, dxb, row.y);
+            }
+            ex.x += dxa * (d[a].x - 0.5 * row.x);
+            ex.y += dxa * (d[a].y - 0.5 * row.y);
+        }
+        const cplx t = c_mul(((const cplx *)A.coef)[i], c_exp(ex));
+        acc[0] += t.x; acc[1] += t.y;
+    }
+    block_sum<2>(acc, red);
+    if (tid == 0) { A.phi[2 * (size_t)k] = acc[0]; A.phi[2 * (size_t)k + 1] = acc[1]; }
+}
+
 }  // namespace
+
+extern "C" int sc_wm_grid_sum(const double *qp, const double *coef, const double *cqq, const double *dvec, int64_t n,
+                              int32_t D, const double *X, int32_t nx, double *phi, void *stream) {
+    if (!qp || !coef || !cqq || !dvec || !X || !phi) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_grid_sum: null argument");
+    if (D < 1 || D > 512) return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_grid_sum: D=%d outside 1..512", D);
+    if (nx <= 0 || n <= 0) return SC_OK;
+    WmGridArgs a{qp, coef, cqq, dvec, n, D, nx, X, phi};
+    hipLaunchKernelGGL(wm_grid_sum_kernel, dim3((unsigned)nx), dim3(256), D * sizeof(double), (hipStream_t)stream, a);
+    return sc_check_launch("sc_wm_grid_sum");
+}
 
 extern "C" int sc_wm_grid(int64_t n, int32_t dim) {
     (void)dim;

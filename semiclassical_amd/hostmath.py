@@ -160,6 +160,7 @@ class WMConstants(object):
         detG0, detGi, detGt = pdet(Gamma_0, np.pi), pdet(Gamma_i, np.pi), pdet(Gamma_t, np.pi)
         detGi0 = pdet(Gamma_0 + Gamma_i, 2 * np.pi)
         self.pre = float(detG0 ** 0.5 * detGt ** 0.25 * detGi ** 0.25 / torch.sqrt(detGi0))     # :1598-1599
+        self.pre_coef = float(detG0 ** 0.25 * detGt ** 0.25 * detGi ** 0.25 / torch.sqrt(detGi0))    # :1408-1409
         e0, V0 = _eigh(Gamma_0)
         keep = e0 > ZERO
         iGamma_0 = torch.einsum('ij,j,kj->ik', V0[:, keep], 1.0 / e0[keep], V0[:, keep])      # :1130

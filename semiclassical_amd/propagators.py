@@ -385,6 +385,7 @@ class HermanKlukPropagator(object):
         check(lib.sc_state_from_reference(ptr(value), self._state, self._stream()))
         torch.cuda.current_stream(self.device).synchronize()     # `value` may be a temporary
         self._corr_step = -1
+        self._wm_export_step = -1
         # the new monodromy blocks may or may not be diagonal: keep the shortcut only if they are
         diag = torch.diagonal(self._mono, dim1=2, dim2=3)
         self._mono_stale = False
@@ -522,6 +523,7 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         self._gwm = lib.sc_wm_grid(n, self.dim)
         self._wpart = torch.zeros((self._gwm, 4), dtype=F64, device=dev)
         self._wm_step, self._wm_has_nac = -1, False
+        self._wm_export_step = -1
         self._wm_nac_bufs = None
         self._build_wm_struct()
 
@@ -533,7 +535,8 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
             n1=ptr(nb[0]) if nb else None, s_n1=ptr(nb[1]) if nb else None, w_n1=ptr(nb[2]) if nb else None,
             inv_scale_a=wm.inv_scale_a, inv_two_pi=wm.inv_two_pi, pre=wm.pre,
             p0n1=self._wm_p0n1 if nb else 0.0, n2=self._wm_n2 if nb else 0.0,
-            detA=ptr(self._detA), detM=ptr(self._detM), sgnA=ptr(self._sgnA), sgnM=ptr(self._sgnM))
+            detA=ptr(self._detA), detM=ptr(self._detM), sgnA=ptr(self._sgnA), sgnM=ptr(self._sgnM),
+            pre_coef=wm.pre_coef)
 
     def _remember_nac(self, potential):
         key = id(potential)
@@ -561,6 +564,42 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
 
     def _after_prefactor(self, track):
         self._wm_launch(track)
+
+    def _export(self):
+        """per-trajectory v_n, C_QQ and d-vector of the current step (no tracking), reference :1391-1432, 1513"""
+        if getattr(self, "_wm_export_step", -1) == self._nsteps:
+            return self._wm_export
+        dev, n, d = self.device, self.ntraj, self.dim
+        coef = torch.zeros(n, dtype=C128, device=dev)
+        cqq = torch.zeros((n, d, d), dtype=C128, device=dev)
+        dvec = torch.zeros((n, d), dtype=C128, device=dev)
+        self._wm.coef_out, self._wm.cqq_out, self._wm.dvec_out = ptr(coef), ptr(cqq), ptr(dvec)
+        try:
+            self._wm_launch(0)
+        finally:
+            self._wm.coef_out, self._wm.cqq_out, self._wm.dvec_out = None, None, None
+        self._wm_export, self._wm_export_step = (coef, cqq, dvec), self._nsteps
+        return self._wm_export
+
+    def coefficients(self):
+        """coefficients v_n of the Gaussians in the WM wavefunction, eqn (75) (reference propagators.py:1391-1432)"""
+        return self._export()[0]
+
+    def wavefunction(self, x):
+        """WM wavefunction psi(x,t) on a spatial grid x (dim,nx) -> complex ndarray (nx,) (reference :1434-1482)"""
+        x = torch.as_tensor(x, dtype=F64)
+        d, nx = x.shape
+        assert d == self.dim, "spatial grid has wrong dimensions"
+        coef, cqq, dvec = self._export()
+        X = x.T.contiguous().to(self.device)
+        phi = torch.zeros(nx, dtype=C128, device=self.device)
+        check(lib.sc_wm_grid_sum(ptr(self._qp), ptr(coef), ptr(cqq), ptr(dvec), self.ntraj, d, ptr(X), nx, ptr(phi),
+                                 self._stream()))
+        return phi.cpu().numpy()
+
+    def norm(self):
+        raise NotImplementedError("WaltonManolopoulosPropagator.norm() (a d' x d' inverse per trajectory pair, "
+                                  "reference propagators.py:1484-1575) is not built yet")
 
     def _launch_correlate(self, slot_ptr, per_trajectory=True):
         # the per-trajectory terms were produced together with the prefactor; recompute (with the stored branch

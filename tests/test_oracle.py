@@ -120,3 +120,18 @@ def test_norm_oracle_matches_reference(name, tag):
     assert cases.rel_err(norm_oracle.coefficients(prop).numpy(), ref[f"{tag}_coeff_{n}"]) < 1e-11
     assert abs(norm_oracle.norm(prop) - float(ref[f"{tag}_norm_{n}"])) < 1e-10
     assert cases.rel_err(norm_oracle.wavefunction(prop, ref[f"{tag}_xgrid"]), ref[f"{tag}_psi_{n}"]) < 1e-10
+
+
+@pytest.mark.parametrize("name,tag", [("wm_1d", "wm1d"), ("wm_as5_chi002", "wmas5"), ("wm_methylium", "wmmet")])
+def test_wm_coefficients_and_wavefunction_oracle_matches_reference(name, tag):
+    from oracle import norm_oracle
+    g, ref = cases.load(name), cases.load("wm_norms")
+    pot, prop = cases.oracle_potential(g), cases.oracle_propagator(g)
+    x = ref[f"{tag}_xgrid"]
+    assert cases.rel_err(norm_oracle.wm_coefficients(prop).numpy(), ref[f"{tag}_coeff_0"]) < 1e-11
+    assert cases.rel_err(norm_oracle.wm_wavefunction(prop, x), ref[f"{tag}_psi_0"]) < 1e-11
+    n = int(ref[f"{tag}_nsteps"])
+    for _ in range(n):
+        prop.step(pot, float(g["dt"]))
+    assert cases.rel_err(norm_oracle.wm_coefficients(prop).numpy(), ref[f"{tag}_coeff_{n}"]) < 1e-9
+    assert cases.rel_err(norm_oracle.wm_wavefunction(prop, x), ref[f"{tag}_psi_{n}"]) < 1e-9

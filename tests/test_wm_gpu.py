@@ -46,3 +46,25 @@ def test_wm_fused_run(name):
     cauto, kic = prop.run(engine_potential(g), float(g["dt"]), int(g["nt"]), float(g["E0"]))
     assert cases.rel_err(cauto, g["cauto"]) < TOL
     assert cases.rel_err(kic, g["kic"]) < TOL
+
+
+@pytest.mark.parametrize("name,tag", [("wm_1d", "wm1d"), ("wm_as5_chi002", "wmas5"), ("wm_methylium", "wmmet")])
+def test_wm_coefficients_and_wavefunction_match_reference(name, tag):
+    """rest of row N1 for WM: coefficients() (eqn 75) and wavefunction() against values produced by the reference"""
+    from tests.engine_cases import engine_potential, engine_propagator
+    g, ref = cases.load(name), cases.load("wm_norms")
+    pot, prop = engine_potential(g), engine_propagator(g)
+    x = cases.T(ref[f"{tag}_xgrid"])
+    assert cases.rel_err(prop.coefficients().cpu().numpy(), ref[f"{tag}_coeff_0"]) < 1e-9
+    assert cases.rel_err(prop.wavefunction(x), ref[f"{tag}_psi_0"]) < 1e-9
+    n = int(ref[f"{tag}_nsteps"])
+    for _ in range(n):
+        prop.step(pot, float(g["dt"]))
+    assert cases.rel_err(prop.coefficients().cpu().numpy(), ref[f"{tag}_coeff_{n}"]) < 1e-8
+    assert cases.rel_err(prop.wavefunction(x), ref[f"{tag}_psi_{n}"]) < 1e-8
+    # the export launch must not disturb the correlation functions of the same step
+    c1 = prop.autocorrelation(float(g["E0"]))
+    prop._wm_export_step = -1
+    prop.coefficients()
+    prop._corr_step = -1
+    assert prop.autocorrelation(float(g["E0"])) == c1
