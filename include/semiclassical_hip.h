@@ -252,6 +252,14 @@ int sc_grid_sum(const double *LqT, const double *PT, const double *pq, const dou
 int sc_wm_grid_sum(const double *qp, const double *coef, const double *cqq, const double *dvec, int64_t n, int32_t D,
                    const double *X, int32_t nx, double *phi, void *stream);
 
+/* O(n^2) pair sum behind WaltonManolopoulosPropagator.norm() (propagators.py:1484-1575), from the per-trajectory
+ * export of sc_wm_correlate and its projections cqqp [n][d'][d'] = U^T CQQ U, dvecp [n][d'] = U^T dvec (complex),
+ * U [D][d'] real.  partials [sc_wm_pair_sum_tiles(n)][4] for sc_reduce_slot.  D <= 64, d' <= 16. */
+int64_t sc_wm_pair_sum_tiles(int64_t n);
+int sc_wm_pair_sum(const double *qp, const double *coef, const double *cqq, const double *dvec, const double *cqqp,
+                   const double *dvecp, const double *U, int64_t n, int32_t D, int32_t dprime, double *partials,
+                   void *stream);
+
 /* Energy-conservation guard on the device, reference propagators.py:385-398 (check_energy_conservation).
  * elog[4] = { <T+V>(t-dt), <T+V>(t), largest |change| seen so far, number of steps logged }.
  * The mean of this step is formed from energy_partials; the host raises the reference's RuntimeError when

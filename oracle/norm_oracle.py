@@ -70,3 +70,35 @@ def wm_wavefunction(prop, x):
     expo = (-0.5 * torch.einsum('inx,ijn,jnx->nx', dx, prop.CQQ, dx) + torch.einsum('in,ijn,jnx->nx', dq, prop.CqQ, dx)
             + 1j / hbar * torch.einsum('in,inx->nx', prop.PIQ, dx))
     return torch.sum(v.unsqueeze(1) * torch.exp(expo), 0).numpy()
+
+
+def wm_norm(prop, chunk=64):
+    """norm of the WM wavefunction (reference propagators.py:1484-1575), block by block over the trajectory pairs"""
+    d, n = prop.dim, prop.ntraj
+    v = wm_coefficients(prop)
+    q, _ = prop.initial_positions_and_momenta()
+    Q, _ = prop.current_positions_and_momenta()
+    q0 = prop.q0.unsqueeze(1).expand_as(q).type(torch.complex128)
+    dvec = torch.einsum('ban,bn->an', prop.CqQ, q0 - q) + 1j / hbar * prop.PIQ
+    U = prop.U.type(torch.complex128)
+    nchunk = n // chunk + 1
+    total = torch.tensor([0.0j])
+    for Qi, di, Ci, vi in zip(torch.chunk(Q, nchunk, dim=1), torch.chunk(dvec, nchunk, dim=1),
+                              torch.chunk(prop.CQQ, nchunk, dim=2), torch.chunk(v, nchunk, dim=0)):
+        ni = vi.shape[0]
+        for Qj, dj, Cj, vj in zip(torch.chunk(Q, nchunk, dim=1), torch.chunk(dvec, nchunk, dim=1),
+                                  torch.chunk(prop.CQQ, nchunk, dim=2), torch.chunk(v, nchunk, dim=0)):
+            nj = vj.shape[0]
+            dQ = (Qj.unsqueeze(1).expand(-1, ni, -1) - Qi.unsqueeze(2).expand(-1, -1, nj)).type(torch.complex128)
+            di_, dj_ = di.unsqueeze(2).expand(-1, -1, nj), dj.unsqueeze(1).expand(-1, ni, -1)
+            Cj_ = Cj.unsqueeze(2).expand(-1, -1, ni, -1)
+            Dij = Ci.unsqueeze(3).expand(-1, -1, -1, nj).conj() + Cj_
+            Dp = torch.einsum('ia,ijmn,jb->abmn', U, Dij, U).permute(2, 3, 0, 1)
+            iD = torch.einsum('ai,ijmn,bj->abmn', U, torch.inverse(Dp).permute(2, 3, 0, 1), U)
+            detD = torch.det(Dp / (2 * np.pi))
+            bij = torch.einsum('abij,bij->aij', Cj_, dQ) + di_.conj() + dj_
+            olap = 1 / torch.sqrt(detD) * torch.exp(-0.5 * torch.einsum('aij,abij,bij->ij', dQ, Cj_, dQ)
+                                                    - torch.einsum('aij,aij->ij', dj_, dQ)
+                                                    + 0.5 * torch.einsum('aij,abij,bij->ij', bij, iD, bij))
+            total += torch.einsum('i,ij,j', vi.conj(), olap, vj)
+    return torch.sqrt(total.real).item()

@@ -88,6 +88,9 @@ SIGNATURES = {
                                   C.c_int32, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     "sc_wm_grid_sum": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32, c_double_p,
                                  C.c_int32, c_double_p, C.c_void_p]),
+    "sc_wm_pair_sum_tiles": (C.c_int64, [C.c_int64]),
+    "sc_wm_pair_sum": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                 C.c_int64, C.c_int32, C.c_int32, c_double_p, C.c_void_p]),
     "sc_gdml_eval": (C.c_int, [P(sc_gdml_model), c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p,
                                C.c_void_p]),
     "sc_dense_grid": (C.c_int, [C.c_int64]),

@@ -204,7 +204,9 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
     MonoArgs a{*st, *hk, inv_mass, hess, 4 * (int64_t)D * D, (int64_t)D * D, dt, mode};
     if (mode == 0) {
         int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
         const int nt = (D + 15) / 16;
         const size_t rk4_lds = ((size_t)2 * 16 * nt * HS + 64 + (size_t)2 * nt * (nt < 4 ? 2 : 1) * 4 * nt * 64) * sizeof(double);
 #define SC_LAUNCH_MONO(NT_, KT_, WGS_)                                                                              \

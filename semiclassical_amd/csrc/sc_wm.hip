@@ -421,7 +421,125 @@ __global__ __launch_bounds__(256) void wm_grid_sum_kernel(WmGridArgs A) {
     if (tid == 0) { A.phi[2 * (size_t)k] = acc[0]; A.phi[2 * (size_t)k + 1] = acc[1]; }
 }
 
+// O(n^2) pair sum behind WaltonManolopoulosPropagator.norm() (reference propagators.py:1484-1575):
+//   norm^2 = sum_ij conj(v_i) O_ij v_j,
+//   O_ij = det(D'_ij / 2 pi)^(-1/2) exp( -1/2 dQ^T CQQ_j dQ - d_j . dQ + 1/2 b^T D_ij^-1 b ),
+//   dQ = Q_j - Q_i,  D_ij = conj(CQQ_i) + CQQ_j,  b = CQQ_j dQ + conj(d_i) + d_j,
+// with D_ij inverted in the non-zero subspace: D' = U^T D U (the host passes the projected C'QQ = U^T CQQ U and
+// d' = U^T d per trajectory), b^T D^-1 b = b'^T D'^-1 b', b' = U^T b.  One thread per pair (16 x 16 pairs per
+// workgroup); the d' x d' system is solved by Gaussian elimination with partial pivoting in per-thread storage.
+#define WMN_MAXD 64
+#define WMN_MAXDP 16
+struct WmPairArgs {
+    const double *qp, *coef, *cqq, *dvec, *cqqp, *dvecp, *U;
+    int64_t n;
+    int D, dp;
+    double *partials;
+};
+
+__global__ __launch_bounds__(256) void wm_pair_sum_kernel(WmPairArgs A) {
+    __shared__ double red[32];
+    const int tid = threadIdx.x, D = A.D, dp = A.dp;
+    const int64_t tiles = (A.n + 15) / 16;
+    const int64_t i = (blockIdx.x / tiles) * 16 + (tid >> 4), j = (blockIdx.x % tiles) * 16 + (tid & 15);
+    double acc[2] = {0.0, 0.0};
+    if (i < A.n && j < A.n) {
+        const double *Qi = A.qp + i * 2 * D, *Qj = A.qp + j * 2 * D;
+        const cplx *Cj = (const cplx *)A.cqq + j * (int64_t)D * D, *dj = (const cplx *)A.dvec + j * D;
+        const cplx *Cpi = (const cplx *)A.cqqp + i * (int64_t)dp * dp, *Cpj = (const cplx *)A.cqqp + j * (int64_t)dp * dp;
+        const cplx *dpi = (const cplx *)A.dvecp + i * dp, *dpj = (const cplx *)A.dvecp + j * dp;
+        cplx w[WMN_MAXD], Dm[WMN_MAXDP * WMN_MAXDP], b[WMN_MAXDP];
+        cplx quad = c_make(0, 0), djq = c_make(0, 0);
+        for (int a = 0; a < D; ++a) {
+            cplx s = c_make(0, 0);
+            for (int c = 0; c < D; ++c) {
+                const double dq = Qj[c] - Qi[c];
+                s.x = fma(Cj[a * D + c].x, dq, s.x); s.y = fma(Cj[a * D + c].y, dq, s.y);
+            }
+            w[a] = s;
+            const double dqa = Qj[a] - Qi[a];
+            quad.x = fma(dqa, s.x, quad.x); quad.y = fma(dqa, s.y, quad.y);
+            djq.x = fma(dqa, dj[a].x, djq.x); djq.y = fma(dqa, dj[a].y, djq.y);
+        }
+        for (int k = 0; k < dp; ++k) {
+            cplx s = c_make(dpi[k].x + dpj[k].x, -dpi[k].y + dpj[k].y);
+            for (int a = 0; a < D; ++a) { const double u = A.U[a * dp + k]; s.x = fma(u, w[a].x, s.x); s.y = fma(u, w[a].y, s.y); }
+            b[k] = s;
+            for (int l = 0; l < dp; ++l)
+                Dm[k * dp + l] = c_make(Cpi[k * dp + l].x + Cpj[k * dp + l].x, -Cpi[k * dp + l].y + Cpj[k * dp + l].y);
+        }
+        // b^T D'^-1 b and det D' : z = D'^-1 b by elimination on the rows (row operations do not change b^T-form
+        // when we keep the ORIGINAL b for the final product)
+        cplx z[WMN_MAXDP];
+        for (int k = 0; k < dp; ++k) z[k] = b[k];
+        cplx det = c_make(1.0, 0.0);
+        bool singular = false;
+        for (int k = 0; k < dp && !singular; ++k) {
+            int piv = k;
+            double best = c_abs2(Dm[k * dp + k]);
+            for (int r = k + 1; r < dp; ++r) { const double m = c_abs2(Dm[r * dp + k]); if (m > best) { best = m; piv = r; } }
+            if (best == 0.0) { singular = true; break; }
+            if (piv != k) {
+                for (int l = 0; l < dp; ++l) { const cplx t = Dm[k * dp + l]; Dm[k * dp + l] = Dm[piv * dp + l]; Dm[piv * dp + l] = t; }
+                const cplx t = z[k]; z[k] = z[piv]; z[piv] = t;
+                det = c_make(-det.x, -det.y);
+            }
+            const cplx p = Dm[k * dp + k], ip = c_inv(p);
+            det = c_mul(det, p);
+            for (int r = k + 1; r < dp; ++r) {
+                const cplx f = c_mul(Dm[r * dp + k], ip);
+                for (int l = k + 1; l < dp; ++l) Dm[r * dp + l] = c_fnma(f, Dm[k * dp + l], Dm[r * dp + l]);
+                z[r] = c_fnma(f, z[k], z[r]);
+            }
+        }
+        if (!singular) {
+            for (int k = dp - 1; k >= 0; --k) {                   // back substitution
+                cplx s = z[k];
+                for (int l = k + 1; l < dp; ++l) s = c_fnma(Dm[k * dp + l], z[l], s);
+                z[k] = c_mul(s, c_inv(Dm[k * dp + k]));
+            }
+            cplx bib = c_make(0, 0);
+            for (int k = 0; k < dp; ++k) bib = c_fma(b[k], z[k], bib);
+            double scale = 1.0;
+            for (int k = 0; k < dp; ++k) scale *= 1.0 / (2.0 * 3.14159265358979323846);
+            const cplx dets = c_scale(det, scale);                 // det(D'/(2 pi))
+            const cplx ex = c_make(-0.5 * quad.x - djq.x + 0.5 * bib.x, -0.5 * quad.y - djq.y + 0.5 * bib.y);
+            const cplx ol = c_mul(c_inv(c_sqrt(dets)), c_exp(ex));
+            const cplx vi = ((const cplx *)A.coef)[i], vj = ((const cplx *)A.coef)[j];
+            const cplx t = c_mul(c_mul(c_conj(vi), ol), vj);
+            acc[0] = t.x; acc[1] = t.y;
+        }
+    }
+    block_sum<2>(acc, red);
+    if (tid == 0) {
+        A.partials[(size_t)blockIdx.x * 4 + 0] = acc[0];
+        A.partials[(size_t)blockIdx.x * 4 + 1] = acc[1];
+        A.partials[(size_t)blockIdx.x * 4 + 2] = 0.0;
+        A.partials[(size_t)blockIdx.x * 4 + 3] = 0.0;
+    }
+}
+
 }  // namespace
+
+extern "C" int64_t sc_wm_pair_sum_tiles(int64_t n) {
+    const int64_t t = (n + 15) / 16;
+    return t * t;
+}
+
+extern "C" int sc_wm_pair_sum(const double *qp, const double *coef, const double *cqq, const double *dvec,
+                              const double *cqqp, const double *dvecp, const double *U, int64_t n, int32_t D,
+                              int32_t dprime, double *partials, void *stream) {
+    if (!qp || !coef || !cqq || !dvec || !cqqp || !dvecp || !U || !partials)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_pair_sum: null argument");
+    if (D < 1 || D > WMN_MAXD || dprime < 1 || dprime > WMN_MAXDP || dprime > D)
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_pair_sum: D=%d d'=%d outside D <= %d, d' <= %d", D, dprime, WMN_MAXD, WMN_MAXDP);
+    if (n <= 0) return SC_OK;
+    const int64_t tiles = sc_wm_pair_sum_tiles(n);
+    if (tiles > 0x7fffffff) return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_pair_sum: n=%lld needs more than 2^31 tiles", (long long)n);
+    WmPairArgs a{qp, coef, cqq, dvec, cqqp, dvecp, U, n, D, dprime, partials};
+    hipLaunchKernelGGL(wm_pair_sum_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    return sc_check_launch("sc_wm_pair_sum");
+}
 
 extern "C" int sc_wm_grid_sum(const double *qp, const double *coef, const double *cqq, const double *dvec, int64_t n,
                               int32_t D, const double *X, int32_t nx, double *phi, void *stream) {

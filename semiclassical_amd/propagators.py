@@ -598,8 +598,21 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         return phi.cpu().numpy()
 
     def norm(self):
-        raise NotImplementedError("WaltonManolopoulosPropagator.norm() (a d' x d' inverse per trajectory pair, "
-                                  "reference propagators.py:1484-1575) is not built yet")
+        """norm |psi| of the WM wavefunction, O(n^2) with a d' x d' inverse per pair (reference :1484-1575)"""
+        dev, n, d = self.device, self.ntraj, self.dim
+        coef, cqq, dvec = self._export()
+        U = self._wm_bufs["U"]                                   # (D, d') real
+        Uc = U.type(C128)
+        cqqp = torch.einsum('ak,nab,bl->nkl', Uc, cqq, Uc).contiguous()      # U^T CQQ U per trajectory
+        dvecp = (dvec @ Uc).contiguous()
+        tiles = lib.sc_wm_pair_sum_tiles(n)
+        partials = torch.empty((tiles, 4), dtype=F64, device=dev)
+        slot = torch.zeros(8, dtype=F64, device=dev)
+        s = self._stream()
+        check(lib.sc_wm_pair_sum(ptr(self._qp), ptr(coef), ptr(cqq), ptr(dvec), ptr(cqqp), ptr(dvecp), ptr(U), n, d,
+                                 U.shape[1], ptr(partials), s))
+        check(lib.sc_reduce_slot(ptr(partials), int(tiles), None, 0, 1.0, ptr(slot), s))
+        return float(torch.sqrt(slot[0]).item())
 
     def _launch_correlate(self, slot_ptr, per_trajectory=True):
         # the per-trajectory terms were produced together with the prefactor; recompute (with the stored branch

@@ -135,3 +135,5 @@ def test_wm_coefficients_and_wavefunction_oracle_matches_reference(name, tag):
         prop.step(pot, float(g["dt"]))
     assert cases.rel_err(norm_oracle.wm_coefficients(prop).numpy(), ref[f"{tag}_coeff_{n}"]) < 1e-9
     assert cases.rel_err(norm_oracle.wm_wavefunction(prop, x), ref[f"{tag}_psi_{n}"]) < 1e-9
+    want = float(ref[f"{tag}_norm_{n}"])
+    assert abs(norm_oracle.wm_norm(prop) - want) < 1e-9 * want

@@ -57,14 +57,31 @@ def test_wm_coefficients_and_wavefunction_match_reference(name, tag):
     x = cases.T(ref[f"{tag}_xgrid"])
     assert cases.rel_err(prop.coefficients().cpu().numpy(), ref[f"{tag}_coeff_0"]) < 1e-9
     assert cases.rel_err(prop.wavefunction(x), ref[f"{tag}_psi_0"]) < 1e-9
+    assert abs(prop.norm() - float(ref[f"{tag}_norm_0"])) < 1e-8 * float(ref[f"{tag}_norm_0"])
     n = int(ref[f"{tag}_nsteps"])
     for _ in range(n):
         prop.step(pot, float(g["dt"]))
     assert cases.rel_err(prop.coefficients().cpu().numpy(), ref[f"{tag}_coeff_{n}"]) < 1e-8
     assert cases.rel_err(prop.wavefunction(x), ref[f"{tag}_psi_{n}"]) < 1e-8
+    assert abs(prop.norm() - float(ref[f"{tag}_norm_{n}"])) < 1e-8 * float(ref[f"{tag}_norm_{n}"])
     # the export launch must not disturb the correlation functions of the same step
     c1 = prop.autocorrelation(float(g["E0"]))
     prop._wm_export_step = -1
     prop.coefficients()
     prop._corr_step = -1
     assert prop.autocorrelation(float(g["E0"])) == c1
+
+
+def test_wm_norm_of_many_trajectories_is_one():
+    """reference tests/test_propagators.py:302-327: |psi| ~ 1 for the 1-D WM wavepacket with enough trajectories"""
+    from tests.engine_cases import engine_potential
+    from semiclassical_amd import propagators as PR
+    g = cases.load("wm_1d")
+    pot = engine_potential(g)
+    Gi = cases.T(g["Gamma_i"])
+    prop = PR.WaltonManolopoulosPropagator(Gi, Gi, float(g["alpha"]), float(g["beta"]), device="cuda")
+    prop.initial_conditions(cases.T(g["q0"]), cases.T(g["p0"]), cases.T(g["Gamma_0"]), ntraj=20000,
+                            generator=torch.Generator().manual_seed(0))
+    for _ in range(20):
+        prop.step(pot, float(g["dt"]))
+    assert abs(prop.norm() - 1.0) < 0.05
