@@ -61,6 +61,29 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Wave-uniform maximum of a 32-bit integer over the wavefront without LDS traffic: DPP row rotations inside each
+// 16-lane row, then one v_readlane per row.  (`__shfl_xor` is a ds_bpermute: ~100 cycles per dependent step.)
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false));      // row_ror:8
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xF, false));      // row_ror:4
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xF, 0xF, false));      // row_ror:2
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xF, 0xF, false));      // row_ror:1
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// Partial-pivoting search over one candidate per lane: `mag` = |a|^2 of this lane's candidate row `row` (or any
+// value with valid = false).  Returns the row of (nearly) the largest magnitude: the comparison key keeps the sign,
+// the exponent and 14 mantissa bits of |a|^2, ties go to the lower lane.  -1 if no lane is valid.
+__device__ __forceinline__ int wave_pivot_row(double mag, int row, bool valid) {
+    const int lane = threadIdx.x & 63;
+    const int key = valid ? ((__double2hiint(mag) & ~63) | (63 - lane)) : -1;
+    const int best = wave_max_i32(key);
+    if (best < 0) return -1;
+    return __builtin_amdgcn_readlane(row, __builtin_amdgcn_readfirstlane(63 - (best & 63)));
+}
+
 // Sum NV values over the whole workgroup; every thread receives the totals.
 // `red` is LDS scratch of at least NV * (blockDim.x / 64) doubles.  Deterministic order.
 template <int NV>

@@ -12,18 +12,11 @@ __device__ cplx lds_lu_det(cplx *A, int d, int *ipiv) {
     cplx det = c_make(1.0, 0.0);
     for (int k = 0; k < d; ++k) {
         if (wave == 0) {
-            double best = -1.0;
-            int bi = k;
-            for (int i = k + lane; i < d; i += 64) {
-                double m = c_abs2(A[i * d + k]);
-                if (m > best) { best = m; bi = i; }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                double ob = __shfl_xor(best, off, 64);
-                int oi = __shfl_xor(bi, off, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
+            // one candidate row per lane (d <= 64): |a_ik|^2 of row i = k + lane, DPP maximum (no ds_bpermute)
+            const int i = k + lane;
+            const bool valid = i < d;
+            int bi = wave_pivot_row(valid ? c_abs2(A[i * d + k]) : 0.0, i, valid);
+            if (bi < 0) bi = k;
             if (bi != k) {
                 for (int j = k + lane; j < d; j += 64) {
                     cplx t = A[k * d + j];

@@ -40,18 +40,11 @@ __device__ cplx lds_gauss_jordan(cplx *aug, int n, cplx *colbuf, int *ipiv) {
     cplx det = c_make(1.0, 0.0);
     for (int k = 0; k < n; ++k) {
         if (tid < 64) {
-            double best = -1.0;
-            int bi = k;
-            for (int i = k + lane; i < n; i += 64) {
-                const double m = c_abs2(aug[i * w2 + k]);
-                if (m > best) { best = m; bi = i; }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(best, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
+            // one candidate row per lane (n <= 64): |a_ik|^2 of row i = k + lane
+            const int i = k + lane;
+            const bool valid = i < n;
+            int bi = wave_pivot_row(valid ? c_abs2(aug[i * w2 + k]) : 0.0, i, valid);
+            if (bi < 0) bi = k;
             if (bi != k) {
                 for (int j = lane; j < w2; j += 64) {
                     const cplx t = aug[k * w2 + j];
@@ -71,9 +64,15 @@ __device__ cplx lds_gauss_jordan(cplx *aug, int n, cplx *colbuf, int *ipiv) {
         __syncthreads();
         for (int j = tid; j < w2; j += nth) aug[k * w2 + j] = c_mul(aug[k * w2 + j], inv);
         __syncthreads();
-        for (int e = tid; e < n * w2; e += nth) {
-            const int i = e / w2, j = e - i * w2;
-            if (i != k) aug[e] = c_fnma(colbuf[i], aug[k * w2 + j], aug[e]);
+        {   // rows strided over groups of `wp` threads (wp = w2 rounded up to a power of two): no integer division
+            int wp = 1;
+            while (wp < w2) wp <<= 1;
+            const int j = tid & (wp - 1), rstep = nth > wp ? nth / wp : 1, r0 = nth > wp ? tid / wp : 0;
+            if (j < w2 && (nth >= wp || tid < wp)) {
+                const cplx rk = aug[k * w2 + j];
+                for (int i = r0; i < n; i += rstep)
+                    if (i != k) aug[i * w2 + j] = c_fnma(colbuf[i], rk, aug[i * w2 + j]);
+            }
         }
         __syncthreads();
     }
