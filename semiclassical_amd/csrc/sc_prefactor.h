@@ -47,37 +47,91 @@ __device__ cplx lds_lu_det(cplx *A, int d, int *ipiv) {
 // General (dense Gamma / rank-deficient) prefactor matrix
 //   mat' = 1/2 [ L1 (Mqq R1 - i hbar Mqp R2) + L2 (Mpp R2 + i/hbar Mpq R1) ]       (d' x d')
 // M planes are read through generic pointers (global or LDS), leading dimension ldm, plane offsets given.
-__device__ void general_prefactor_matrix(const sc_hk_consts &hk, const double *Mqq, const double *Mqp,
-                                         const double *Mpq, const double *Mpp, int ldm, cplx *X, cplx *mat) {
+// Both products are register tiled (3 x 3 outputs per thread): every operand element fetched from L2 / LDS feeds
+// three multiply-adds instead of one -- the untiled loops were bound by the load instructions, not the FMAs.
+template <int PF_T>
+__device__ void general_prefactor_matrix_t(const sc_hk_consts &hk, const double *Mqq, const double *Mqp,
+                                           const double *Mpq, const double *Mpp, int ldm, cplx *X, cplx *mat) {
     const int D = hk.dim, dp = hk.dprime, tid = threadIdx.x, nth = blockDim.x;
     const cplx *L1 = (const cplx *)hk.L1, *L2 = (const cplx *)hk.L2;
     const cplx *R1 = (const cplx *)hk.R1, *R2 = (const cplx *)hk.R2;
+    const int ta = (D + PF_T - 1) / PF_T, tj = (dp + PF_T - 1) / PF_T;       // tiles over (D, d') and (d', d')
     for (int pass = 0; pass < 2; ++pass) {
         const double *Ma = pass == 0 ? Mqq : Mpp, *Mb = pass == 0 ? Mqp : Mpq;
         const cplx *Ra = pass == 0 ? R1 : R2, *Rb = pass == 0 ? R2 : R1;
         const cplx fb = pass == 0 ? c_make(0.0, -SC_HBAR) : c_make(0.0, 1.0 / SC_HBAR);
         const cplx *L = pass == 0 ? L1 : L2;
-        for (int e = tid; e < D * dp; e += nth) {
-            const int a = e / dp, j = e - a * dp;
-            cplx s1 = c_make(0, 0), s2 = c_make(0, 0);
+        // X = Ma Ra + fb Mb Rb   (D x d')
+        for (int t = tid; t < ta * tj; t += nth) {
+            const int a0 = (t / tj) * PF_T, j0 = (t % tj) * PF_T;
+            cplx s1[PF_T][PF_T], s2[PF_T][PF_T];
+#pragma unroll
+            for (int u = 0; u < PF_T; ++u)
+#pragma unroll
+                for (int v = 0; v < PF_T; ++v) { s1[u][v] = c_make(0, 0); s2[u][v] = c_make(0, 0); }
             for (int b = 0; b < D; ++b) {
-                const double ma = Ma[a * ldm + b], mb = Mb[a * ldm + b];
-                const cplx ra = Ra[b * dp + j], rb = Rb[b * dp + j];
-                s1.x = fma(ma, ra.x, s1.x); s1.y = fma(ma, ra.y, s1.y);
-                s2.x = fma(mb, rb.x, s2.x); s2.y = fma(mb, rb.y, s2.y);
+                double ma[PF_T], mb[PF_T];
+                cplx ra[PF_T], rb[PF_T];
+#pragma unroll
+                for (int u = 0; u < PF_T; ++u) {
+                    const int a = min(a0 + u, D - 1), j = min(j0 + u, dp - 1);
+                    ma[u] = Ma[a * ldm + b]; mb[u] = Mb[a * ldm + b];
+                    ra[u] = Ra[b * dp + j]; rb[u] = Rb[b * dp + j];
+                }
+#pragma unroll
+                for (int u = 0; u < PF_T; ++u)
+#pragma unroll
+                    for (int v = 0; v < PF_T; ++v) {
+                        s1[u][v].x = fma(ma[u], ra[v].x, s1[u][v].x); s1[u][v].y = fma(ma[u], ra[v].y, s1[u][v].y);
+                        s2[u][v].x = fma(mb[u], rb[v].x, s2[u][v].x); s2[u][v].y = fma(mb[u], rb[v].y, s2[u][v].y);
+                    }
             }
-            X[e] = c_add(s1, c_mul(fb, s2));
+#pragma unroll
+            for (int u = 0; u < PF_T; ++u)
+#pragma unroll
+                for (int v = 0; v < PF_T; ++v)
+                    if (a0 + u < D && j0 + v < dp) X[(a0 + u) * dp + j0 + v] = c_add(s1[u][v], c_mul(fb, s2[u][v]));
         }
         __syncthreads();
-        for (int e = tid; e < dp * dp; e += nth) {
-            const int i = e / dp, j = e - i * dp;
-            cplx s = c_make(0, 0);
-            for (int a = 0; a < D; ++a) s = c_fma(L[i * D + a], X[a * dp + j], s);
-            s = c_scale(s, 0.5);
-            mat[e] = pass == 0 ? s : c_add(mat[e], s);
+        // mat (+)= 1/2 L X   (d' x d')
+        for (int t = tid; t < tj * tj; t += nth) {
+            const int i0 = (t / tj) * PF_T, j0 = (t % tj) * PF_T;
+            cplx s[PF_T][PF_T];
+#pragma unroll
+            for (int u = 0; u < PF_T; ++u)
+#pragma unroll
+                for (int v = 0; v < PF_T; ++v) s[u][v] = c_make(0, 0);
+            for (int a = 0; a < D; ++a) {
+                cplx l[PF_T], x[PF_T];
+#pragma unroll
+                for (int u = 0; u < PF_T; ++u) {
+                    l[u] = L[min(i0 + u, dp - 1) * D + a];
+                    x[u] = X[a * dp + min(j0 + u, dp - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < PF_T; ++u)
+#pragma unroll
+                    for (int v = 0; v < PF_T; ++v) s[u][v] = c_fma(l[u], x[v], s[u][v]);
+            }
+#pragma unroll
+            for (int u = 0; u < PF_T; ++u)
+#pragma unroll
+                for (int v = 0; v < PF_T; ++v)
+                    if (i0 + u < dp && j0 + v < dp) {
+                        const int e = (i0 + u) * dp + j0 + v;
+                        const cplx h = c_scale(s[u][v], 0.5);
+                        mat[e] = pass == 0 ? h : c_add(mat[e], h);
+                    }
         }
         __syncthreads();
     }
+}
+
+// small matrices keep one output per thread (a 3 x 3 tiling would leave most of the workgroup idle)
+__device__ void general_prefactor_matrix(const sc_hk_consts &hk, const double *Mqq, const double *Mqp,
+                                         const double *Mpq, const double *Mpp, int ldm, cplx *X, cplx *mat) {
+    if (hk.dim * hk.dprime >= 4 * (int)blockDim.x) general_prefactor_matrix_t<3>(hk, Mqq, Mqp, Mpq, Mpp, ldm, X, mat);
+    else general_prefactor_matrix_t<1>(hk, Mqq, Mqp, Mpq, Mpp, ldm, X, mat);
 }
 
 }  // namespace
