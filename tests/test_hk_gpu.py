@@ -104,6 +104,42 @@ def test_hk_matches_oracle_fresh_inputs():
     assert cases.rel_err(c, rc) < TOL and cases.rel_err(k, rk) < TOL
 
 
+@pytest.mark.parametrize("zero_modes", [0, 2])
+def test_dense_and_singular_width_matrices_vs_oracle(zero_modes):
+    """separable potential, but DENSE width matrices (rotated, optionally rank deficient as in the reference's
+    singular-Gamma tests, tests/test_propagators.py:73-113): the general LDS kernel, the projected prefactor and the
+    dense-matrix overlap / NAC kernels against the CPU oracle on fresh inputs; HK and WM"""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(11 + zero_modes)
+    D, n, nt, dt = 6, 200, 12, 3.0
+    omega = torch.from_numpy(np.sort(rng.uniform(600, 2500, D)) / 219474.63)
+    S = torch.from_numpy(rng.uniform(0.05, 0.3, D) * rng.choice([-1, 1], D))
+    nac = torch.from_numpy(rng.normal(0, 1e-3, D))
+    chi = torch.full((D,), 0.01)
+    q0 = torch.sqrt(2 * abs(S) / omega) * torch.sign(S)
+    p0 = 0.0 * q0
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    w = omega.numpy() * rng.uniform(0.7, 1.4, D)
+    w[:zero_modes] = 0.0                                         # zero modes of the width matrices
+    G = torch.from_numpy(Q @ np.diag(w) @ Q.T)
+    G = 0.5 * (G + G.T)
+    E0 = float(0.5 * omega.sum())
+    for kind in ("HK", "WM"):
+        if kind == "HK":
+            ref, prop = orc.HKOracle(G, G), PR.HermanKlukPropagator(G, G, device="cuda")
+        else:
+            ref, prop = orc.WMOracle(G, G, 50.0, 50.0), PR.WaltonManolopoulosPropagator(G, G, 50.0, 50.0, device="cuda")
+        torch.manual_seed(5)
+        ref.initial_conditions(q0, p0, G, ntraj=n)
+        rc, rk = orc.run_loop(ref, orc.MorseOracle(omega, chi.clone(), nac), dt, nt, E0)
+        prop.set_initial_conditions(q0, p0, G, ref.zi, ref.probi)
+        assert prop._pre.dprime == D - zero_modes and not prop._pre.diag
+        c, k = prop.run(P.MorsePotential(omega, chi.clone(), nac), dt, nt, E0)
+        assert cases.rel_err(c, rc) < 1e-8 and cases.rel_err(k, rk) < 1e-8, kind
+
+
 def test_energy_guard_raises_reference_error():
     """a time step far too large violates <T+V> conservation: same RuntimeError text as the reference"""
     from tests.engine_cases import engine_potential, engine_propagator
