@@ -9,7 +9,7 @@ assertion.  The time loop itself is ``propagator.run`` (no host synchronisation 
     python -m semiclassical_amd.driver dynamics input.json [--cuda ID]
     python -m semiclassical_amd.driver rates input.json
 
-Not carried over: extxyz export, ``calc_norm_every``, plotting (outside the hot path).
+Not carried over: extxyz export and plotting (outside the hot path).
 Potential types: "harmonic", "anharmonic AS", "gdml" (cli.py:178-303).
 """
 import argparse
@@ -117,7 +117,18 @@ def run_semiclassical_dynamics(task, device='cuda'):
         else:
             propagator = propagators.HermanKlukPropagator(Gamma_i, Gamma_t, device=device)
         propagator.initial_conditions(q0, p0, Gamma_0, ntraj=num_samples)
-        autocorrelation_, ic_correlation_ = propagator.run(potential, dt, nt, energy0_es=en_zpt)
+        calc_norm_every = task.get('calc_norm_every', 0)
+        if calc_norm_every > 0:
+            # convergence diagnostic of cli.py:424-429 (O(ntraj^2)): the fused loop is cut at the steps where the
+            # norm is wanted
+            parts = []
+            for t0 in range(0, nt, calc_norm_every):
+                logger.info(f" time/fs= {times[t0] * units.autime_to_fs}  norm= {propagator.norm():9.6f}")
+                parts.append(propagator.run(potential, dt, min(calc_norm_every, nt - t0), energy0_es=en_zpt))
+            autocorrelation_ = np.concatenate([c for c, _ in parts])
+            ic_correlation_ = np.concatenate([k for _, k in parts])
+        else:
+            autocorrelation_, ic_correlation_ = propagator.run(potential, dt, nt, energy0_es=en_zpt)
         assert not np.isnan(autocorrelation_).any(), f"encountered NaN's in autocorrelation : {autocorrelation_}"
         assert not np.isnan(ic_correlation_).any(), f"encountered NaN's in IC correlation : {ic_correlation_}"
 

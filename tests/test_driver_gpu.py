@@ -39,3 +39,26 @@ def test_dynamics_and_rates_task(tmp_path):
     driver.calculate_rates({"task": "rates", "correlations": str(out), "rates": str(out)})
     d3 = np.load(out)
     assert "ic_rate" in d3 and d3["ic_rate"].shape == d3["energies"].shape and (d3["energies"] >= 0).all()
+
+
+def test_calc_norm_every_does_not_change_the_correlations(tmp_path, caplog):
+    """cli.py:424-429: the norm diagnostic cuts the fused loop into segments; results must be those of one loop"""
+    import logging
+    from semiclassical_amd import driver
+    g = cases.load("hk_as5_chi002")
+    model = tmp_path / "AS_model.dat"
+    rows = np.vstack((g["omega"] * 219474.63, 0.5 * g["omega"] * g["q0"] ** 2 * np.sign(g["q0"]), g["nac"],
+                      np.full(5, 0.02))).T
+    np.savetxt(model, rows)
+    res = []
+    for every in (0, 7):
+        out = tmp_path / f"c{every}.npz"
+        task = {"task": "dynamics", "potential": {"type": "anharmonic AS", "model_file": str(model)},
+                "propagator": "HK", "batch_size": 500, "num_trajectories": 500, "num_steps": 20, "time_step_fs": 0.04,
+                "results": {"correlations": str(out)}, "manual_seed": 3, "calc_norm_every": every}
+        with caplog.at_level(logging.INFO, logger="semiclassical_amd.driver"):
+            driver.run_semiclassical_dynamics(task, device="cuda")
+        res.append(dict(np.load(out)))
+    assert np.allclose(res[0]["autocorrelation"], res[1]["autocorrelation"], rtol=1e-13, atol=0)
+    assert np.allclose(res[0]["ic_correlation"], res[1]["ic_correlation"], rtol=1e-13, atol=0)
+    assert sum("norm=" in r.getMessage() for r in caplog.records) == 3          # t = 0, 7, 14
