@@ -55,10 +55,26 @@ __device__ __forceinline__ cplx c_exp(cplx z) {
     return make_double2(e * c, e * s);
 }
 
+// Sum over the wavefront, result in every lane.  DPP rotations inside each 16-lane row (64-bit values move as two
+// 32-bit DPP moves), then one v_readlane pair per row: no LDS traffic (`__shfl_xor` is a ds_bpermute, ~100 cycles
+// per dependent step, 12 of them for a double).  Fixed order => deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_mov_f64<0x128>(v);      // row_ror:8
+    v += dpp_mov_f64<0x124>(v);      // row_ror:4
+    v += dpp_mov_f64<0x122>(v);      // row_ror:2
+    v += dpp_mov_f64<0x121>(v);      // row_ror:1
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // Wave-uniform maximum of a 32-bit integer over the wavefront without LDS traffic: DPP row rotations inside each

@@ -34,10 +34,10 @@ __device__ __forceinline__ int pair_index(int a, int b) {      // a != b; torch.
 }
 
 struct GdmlLds {
-    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *XJ, *AJ, *red;
+    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *XJ, *AJ, *xsL, *aL, *red;
 };
 
-#define GDML_CHUNK 32
+#define GDML_CHUNK 16
 
 __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt) {
     GdmlLds L;
@@ -54,11 +54,14 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt) {
     L.grad = f; f += 3 * N;
     L.XJ = f;   f += GDML_CHUNK * 3 * N;
     L.AJ = f;   f += GDML_CHUNK * 3 * N;
+    L.xsL = f;  f += GDML_CHUNK * Dd;       // training descriptors / coefficients of the chunk: staged once (coalesced),
+    L.aL = f;   f += GDML_CHUNK * Dd;       // then read 2 (N-1) times each by the J^T products
     return L;
 }
 
 size_t gdml_lds_doubles(int N, int Dd, int Mt) {
-    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + 2 * (size_t)GDML_CHUNK * 3 * N;
+    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + 2 * (size_t)GDML_CHUNK * 3 * N +
+           2 * (size_t)GDML_CHUNK * Dd;
 }
 
 // V (without origin), grad[3N] (LDS, L.grad) and hess[3N][3N] (global, row-major) at the geometry in L.pos.
@@ -79,20 +82,30 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     __syncthreads();
     // ---- per-training-point scalars (one wave per m, lanes over the descriptor)
     double esum = 0.0, ssum = 0.0;
-    for (int m = wave; m < Mt; m += nw) {
-        const double *xs = G.xs_train + (size_t)m * Dd, *A = G.jx_alphas + (size_t)m * Dd;
-        double s2 = 0.0, sa = 0.0;
+    // four training points per wavefront and pass: their 8 row loads are in flight together and lanes 0..3 do the
+    // scalar tail (sqrt, exp) of one point each
+    for (int mq = 4 * wave; mq < Mt; mq += 4 * nw) {
+        double s2[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0};
         for (int d = lane; d < Dd; d += 64) {
-            const double xd = L.x[d] - xs[d];
-            s2 = fma(xd, xd, s2);
-            sa = fma(xd, A[d], sa);
+            const double xv = L.x[d];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t row = (size_t)min(mq + i, Mt - 1) * Dd + d;
+                const double xd = xv - G.xs_train[row];
+                s2[i] = fma(xd, xd, s2[i]);
+                sa[i] = fma(xd, G.jx_alphas[row], sa[i]);
+            }
         }
-        s2 = wave_sum(s2); sa = wave_sum(sa);
-        if (lane == 0) {
-            const double dist = sqrt(s2), e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s2[i] = wave_sum(s2[i]); sa[i] = wave_sum(sa[i]); }
+        const int m = mq + lane;
+        if (lane < 4 && m < Mt) {
+            const double s2m = lane == 0 ? s2[0] : lane == 1 ? s2[1] : lane == 2 ? s2[2] : s2[3];
+            const double sam = lane == 0 ? sa[0] : lane == 1 ? sa[1] : lane == 2 ? sa[2] : sa[3];
+            const double dist = sqrt(s2m), e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
             const double f = e * (1.0 + q * dist) / (q * q);
-            L.fm[m] = f; L.em[m] = e; L.wm[m] = e * sa * q / dist; L.ea[m] = e * sa;
-            esum += f * sa; ssum += e * sa;
+            L.fm[m] = f; L.em[m] = e; L.wm[m] = e * sam * q / dist; L.ea[m] = e * sam;
+            esum += f * sam; ssum += e * sam;
         }
     }
     double red2[2] = {esum, ssum};
@@ -100,11 +113,22 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     const double energy = red2[0] * G.std + G.c, S = red2[1];
     __syncthreads();
     // ---- gradient in descriptor space, then Cartesian gradient
+    // every wavefront takes a slice of the training points (lanes over the descriptor: coalesced rows), the per-wave
+    // partial sums meet in LDS (L.XJ is free at this point; nw * Dd <= GDML_CHUNK * 3N is checked by the host)
+    for (int d0 = 0; d0 < Dd; d0 += 64) {
+        const int d = d0 + lane;
+        double g = 0.0;
+        if (d < Dd) {
+            const double xv = L.x[d];
+            for (int m = wave; m < Mt; m += nw)
+                g += L.fm[m] * G.jx_alphas[(size_t)m * Dd + d] - L.ea[m] * (xv - G.xs_train[(size_t)m * Dd + d]);
+            L.XJ[wave * Dd + d] = g;
+        }
+    }
+    __syncthreads();
     for (int d = tid; d < Dd; d += nth) {
         double g = 0.0;
-        const double xv = L.x[d];
-        for (int m = 0; m < Mt; ++m)
-            g += L.fm[m] * G.jx_alphas[(size_t)m * Dd + d] - L.ea[m] * (xv - G.xs_train[(size_t)m * Dd + d]);
+        for (int w = 0; w < nw; ++w) g += L.XJ[w * Dd + d];
         L.gx[d] = g;
     }
     __syncthreads();
@@ -135,19 +159,45 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         for (int m0 = 0; m0 < Mt; m0 += GDML_CHUNK) {
             const int mc = min(GDML_CHUNK, Mt - m0);
             __syncthreads();
-            // XJ_m = J^T xd_m, AJ_m = J^T A_m for the chunk
-            for (int e = tid; e < mc * X; e += nth) {
-                const int mm = e / X, xi = e - mm * X, at = xi / 3, u = xi - 3 * at, m = m0 + mm;
-                const double *xs = G.xs_train + (size_t)m * Dd, *A = G.jx_alphas + (size_t)m * Dd;
-                double sx = 0.0, sa = 0.0;
-                for (int c = 0; c < N; ++c) {
-                    if (c == at) continue;
-                    const int d = pair_index(at, c);
-                    const double j = (at > c) ? L.jd[3 * d + u] : -L.jd[3 * d + u];
-                    sx = fma(j, L.x[d] - xs[d], sx);
-                    sa = fma(j, A[d], sa);
+            // the chunk's training rows m0 .. m0+mc-1 are contiguous: coalesced global -> LDS.  (Read straight from L2
+            // by the J^T products they cost 8 scattered bytes per multiply-add: the launch was L2-bandwidth bound.)
+            for (int e = tid; e < mc * Dd; e += nth) {
+                L.xsL[e] = G.xs_train[(size_t)m0 * Dd + e];
+                L.aL[e] = G.jx_alphas[(size_t)m0 * Dd + e];
+            }
+            __syncthreads();
+            // XJ_m = J^T xd_m, AJ_m = J^T A_m for the chunk.  Thread = (Cartesian component xi, group g of training
+            // points mm = g, g + NG, ...): the Jacobian entry of a partner atom is fetched once per group, not per m.
+            {
+                const int NG = nth / X > 0 ? nth / X : 1;             // groups of training points
+                constexpr int MPT = 4;                                // training points per thread and pass
+                if (tid < NG * X) {
+                    const int xi = tid % X, g = tid / X, at = xi / 3, u = xi - 3 * at;
+                    for (int mb = g; mb < mc; mb += NG * MPT) {
+                        double sx[MPT], sa[MPT];
+#pragma unroll
+                        for (int i = 0; i < MPT; ++i) { sx[i] = 0.0; sa[i] = 0.0; }
+                        for (int c = 0; c < N; ++c) {
+                            if (c == at) continue;
+                            const int d = pair_index(at, c);
+                            const double j = (at > c) ? L.jd[3 * d + u] : -L.jd[3 * d + u];
+                            const double xd = L.x[d];
+#pragma unroll
+                            for (int i = 0; i < MPT; ++i) {
+                                const int mm = mb + i * NG;
+                                if (mm < mc) {
+                                    sx[i] = fma(j, xd - L.xsL[mm * Dd + d], sx[i]);
+                                    sa[i] = fma(j, L.aL[mm * Dd + d], sa[i]);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < MPT; ++i) {
+                            const int mm = mb + i * NG;
+                            if (mm < mc) { L.XJ[mm * X + xi] = sx[i]; L.AJ[mm * X + xi] = sa[i]; }
+                        }
+                    }
                 }
-                L.XJ[e] = sx; L.AJ[e] = sa;
             }
             __syncthreads();
             if (own) {
@@ -293,6 +343,8 @@ int check_model(const sc_gdml_model *g, const char *who) {
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: descriptor size %d does not match %d atoms", who, g->n_desc, g->n_atoms);
     if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8 > 160 * 1024)
         return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d, M=%d) needs more than 160 KiB of LDS", who, g->n_atoms, g->n_train);
+    if (4 * g->n_desc > GDML_CHUNK * 3 * g->n_atoms)      // per-wave partial sums of the descriptor gradient live in L.XJ
+        return sc_fail(SC_ERR_UNSUPPORTED, "%s: N=%d atoms exceed the staging buffers", who, g->n_atoms);
     return SC_OK;
 }
 
