@@ -216,6 +216,13 @@ int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, double *ene
  * T+V (energy_partials[sc_dense_grid()]).  With sc_dense_mono_step it replaces _rk4_step / EquationsOfMotion.f
  * (propagators.py:86-119, 313-383) for potentials whose Hessian is dense and position dependent. */
 int sc_dense_grid(int64_t n);
+/* The same RK4 bookkeeping of (q, p, S) for potentials the CALLER evaluates (any object with the reference's potential
+ * protocol, potentials.py:41-204): per stage, sc_stage_point writes the stage positions r_out [n][D], the caller
+ * evaluates V [n], grad [n][D] (and copies its Hessians into sc->hess[n][stage][D][D]), sc_stage_consume advances the
+ * slopes / sums exactly as sc_gdml_stage does (energy_partials[sc_dense_grid()] at stage 3). */
+int sc_stage_point(const sc_state *st, const sc_dense_scratch *sc, double dt, int32_t stage, double *r_out, void *stream);
+int sc_stage_consume(const sc_state *st, const sc_dense_scratch *sc, const double *inv_mass, const double *V,
+                     const double *grad, double dt, int32_t stage, double *energy_partials, void *stream);
 int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const sc_dense_scratch *sc, double dt, int32_t stage,
                   double *energy_partials, void *stream);
 

@@ -189,7 +189,87 @@ __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
     }
 }
 
+// ---- RK4 of (q, p, S) for potentials the CALLER evaluates (generic Python potentials: SURVEY.md section 8b, "generic
+// Python potentials take the unfused path").  Per stage: sc_stage_point writes the stage positions, the caller
+// evaluates V, grad, hess there with its own code, sc_stage_consume does the bookkeeping of the reference's RK4
+// (propagators.py:86-119) and of EquationsOfMotion.f (:313-383: q' = p/m, p' = -grad, S' = T - V, <T+V> at the
+// k4 stage).  One wavefront per trajectory, lane = coordinate.
+struct StageArgs2 {
+    sc_state st;
+    sc_dense_scratch sc;
+    const double *inv_mass, *V, *grad;      // V [n], grad [n][D] (trajectory-major)
+    double *r_out;                           // [n][D]
+    double dt;
+    int stage;
+    double *epart;
+};
+
+__global__ __launch_bounds__(256) void stage_point_kernel(StageArgs2 A) {
+    const int D = A.st.dim, s = A.stage;
+    const double c = (s == 0) ? 0.0 : (s == 3 ? A.dt : 0.5 * A.dt);
+    const int64_t total = A.st.n * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tr = e / D;
+        const int i = (int)(e - tr * D);
+        A.r_out[e] = A.st.qp[tr * 2 * D + i] + (s ? c * A.sc.kprev[tr * 2 * D + i] : 0.0);
+    }
+}
+
+__global__ __launch_bounds__(256) void stage_consume_kernel(StageArgs2 A) {
+    const int D = A.st.dim, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, s = A.stage;
+    const double dt = A.dt, c = (s == 0) ? 0.0 : (s == 3 ? dt : 0.5 * dt), w = (s == 0 || s == 3) ? 1.0 : 2.0;
+    const double h6 = dt / 6.0;
+    __shared__ double wsum[4];
+    double esum = 0.0;
+    for (int64_t tr = (int64_t)blockIdx.x * 4 + wave; tr < A.st.n; tr += (int64_t)gridDim.x * 4) {
+        double *qp = A.st.qp + tr * 2 * D;
+        double *kprev = A.sc.kprev + tr * 2 * D, *ksum = A.sc.ksum + tr * 2 * D;
+        const double *g = A.grad + tr * D;
+        double tk = 0.0;
+        for (int i = lane; i < D; i += 64) {
+            const double ps = qp[D + i] + (s ? c * kprev[D + i] : 0.0);       // momentum at the stage point
+            const double im = A.inv_mass[i], kq = ps * im, kp = -g[i];
+            tk += 0.5 * ps * ps * im;
+            kprev[i] = kq; kprev[D + i] = kp;
+            const double sq = (s ? ksum[i] : 0.0) + w * kq, sp = (s ? ksum[D + i] : 0.0) + w * kp;
+            if (s < 3) { ksum[i] = sq; ksum[D + i] = sp; }
+            else { qp[i] += h6 * sq; qp[D + i] += h6 * sp; }
+        }
+        tk = wave_sum(tk);
+        if (lane == 0) {
+            const double e = A.V[tr], ds = tk - e, acc = (s ? A.sc.ssum[tr] : 0.0) + w * ds;
+            if (s < 3) A.sc.ssum[tr] = acc;
+            else { A.st.act[tr] += h6 * acc; esum += tk + e; }
+        }
+    }
+    if (lane == 0) wsum[wave] = esum;
+    __syncthreads();
+    if (threadIdx.x == 0 && A.epart && s == 3) A.epart[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 }  // namespace
+
+extern "C" int sc_stage_point(const sc_state *st, const sc_dense_scratch *sc, double dt, int32_t stage, double *r_out,
+                              void *stream) {
+    if (!st || !sc || !sc->kprev || !r_out) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_stage_point: null argument");
+    if (stage < 0 || stage > 3) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_stage_point: stage %d", stage);
+    if (st->n <= 0) return SC_OK;
+    StageArgs2 a{*st, *sc, nullptr, nullptr, nullptr, r_out, dt, stage, nullptr};
+    const int64_t blocks = (st->n * st->dim + 255) / 256;
+    hipLaunchKernelGGL(stage_point_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, a);
+    return sc_check_launch("sc_stage_point");
+}
+
+extern "C" int sc_stage_consume(const sc_state *st, const sc_dense_scratch *sc, const double *inv_mass, const double *V,
+                                const double *grad, double dt, int32_t stage, double *energy_partials, void *stream) {
+    if (!st || !sc || !sc->kprev || !sc->ksum || !sc->ssum || !inv_mass || !V || !grad)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_stage_consume: null argument");
+    if (stage < 0 || stage > 3) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_stage_consume: stage %d", stage);
+    if (st->n <= 0) return SC_OK;
+    StageArgs2 a{*st, *sc, inv_mass, V, grad, nullptr, dt, stage, energy_partials};
+    hipLaunchKernelGGL(stage_consume_kernel, dim3(sc_dense_grid(st->n)), dim3(256), 0, (hipStream_t)stream, a);
+    return sc_check_launch("sc_stage_consume");
+}
 
 extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
                                   double dt, int32_t mode, void *stream) {

@@ -201,6 +201,9 @@ class HermanKlukPropagator(object):
         if hasattr(potential, "_gdml_model"):
             self._sync_dense_mono(leave_diagonal=True)
             nblocks = self._launch_dense_step(potential, dt, s)
+        elif not hasattr(potential, "_descriptor"):
+            self._sync_dense_mono(leave_diagonal=True)
+            nblocks = self._launch_generic_step(potential, dt, s)
         else:
             desc = self._potential_descriptor(potential)
             if self._shortcut_applies(desc):
@@ -233,6 +236,16 @@ class HermanKlukPropagator(object):
 
     def _launch_dense_step(self, potential, dt, s):
         """unfused RK4 step for a dense, position-dependent Hessian: four stage kernels + the monodromy kernel"""
+        self._dense_scratch()
+        with torch.cuda.device(self.device):
+            model = potential._gdml_model(self.device)
+        for stage in range(4):
+            check(lib.sc_gdml_stage(model, self._state, self._dense, dt, stage, ptr(self._epart), s))
+        check(lib.sc_dense_mono_step(self._state, self._hk, model.inv_mass, ptr(self._dense_bufs[0]), dt, 0, s))
+        return self._gdense
+
+    def _dense_scratch(self):
+        """scratch of the unfused dense path: stage Hessians, slopes of the previous stage, weighted slope sums"""
         n, d = self.ntraj, self.dim
         if getattr(self, "_dense", None) is None:
             dev = self.device
@@ -243,11 +256,33 @@ class HermanKlukPropagator(object):
             self._gdense = lib.sc_dense_grid(n)
             if self._gdense > self._epart.numel():
                 self._epart = torch.zeros(self._gdense, dtype=F64, device=dev)
-        with torch.cuda.device(self.device):
-            model = potential._gdml_model(self.device)
+        return self._dense
+
+    def _launch_generic_step(self, potential, dt, s):
+        """Any object with the reference's potential protocol (potentials.py:41-204: ``harmonic_approximation(r) ->
+        V (n,), grad (D,n), hess (D,D,n)``, ``masses()``): the potential is evaluated by ITS OWN torch code on the
+        device at the four RK4 stage points; the RK4 bookkeeping, the monodromy GEMMs and the prefactor stay in HIP
+        (generic Python potentials take the unfused path)."""
+        n, d = self.ntraj, self.dim
+        dense = self._dense_scratch()
+        key = id(potential)
+        if getattr(self, "_generic_key", None) != key:
+            self._generic_inv_mass = (1.0 / hostmath.as_f64(potential.masses())).to(self.device).contiguous()
+            self._generic_r = torch.empty((n, d), dtype=F64, device=self.device)
+            self._generic_key = key
+        r, inv_mass = self._generic_r, self._generic_inv_mass
         for stage in range(4):
-            check(lib.sc_gdml_stage(model, self._state, self._dense, dt, stage, ptr(self._epart), s))
-        check(lib.sc_dense_mono_step(self._state, self._hk, model.inv_mass, ptr(self._dense_bufs[0]), dt, 0, s))
+            check(lib.sc_stage_point(self._state, dense, dt, stage, ptr(r), s))
+            V, grad, hess = potential.harmonic_approximation(r.t())
+            assert V.shape == (n,) and grad.shape == (d, n) and hess.shape == (d, d, n), \
+                "harmonic_approximation has to return V (n,), grad (D,n), hess (D,D,n)"
+            Vc = V.to(F64).contiguous()
+            gt = grad.to(F64).t().contiguous()
+            # the monodromy kernel takes the stage Hessian image as A[i][k] = image[k][i]: store the transpose
+            self._dense_bufs[0][:, stage].copy_(hess.permute(2, 1, 0))
+            check(lib.sc_stage_consume(self._state, dense, ptr(inv_mass), ptr(Vc), ptr(gt), dt, stage,
+                                       ptr(self._epart), s))
+        check(lib.sc_dense_mono_step(self._state, self._hk, ptr(inv_mass), ptr(self._dense_bufs[0]), dt, 0, s))
         return self._gdense
 
     def _after_prefactor(self, track):

@@ -1,0 +1,77 @@
+"""Generic Python potentials ("generic Python potentials take the unfused path"): an object that
+only implements the reference's potential protocol in torch is evaluated by its own code at the RK4 stage points, the
+rest of the step runs in HIP.  Checked against the CPU oracle driving the very same class."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+torch.set_default_dtype(torch.float64)
+
+
+class CoupledQuarticPotential(object):
+    """V = 1/2 sum_a w_a^2 r_a^2 + lam (sum_a r_a r_{a+1})^2 : non-separable, Hessian dense and position dependent"""
+
+    def __init__(self, omega, lam, masses, nac):
+        self.omega, self.lam, self._masses, self.nac = omega, lam, masses, nac
+
+    def dimensions(self):
+        return len(self.omega)
+
+    def masses(self):
+        return self._masses
+
+    def harmonic_approximation(self, r):
+        w2 = (self.omega ** 2).to(r.device).unsqueeze(1)
+        d, n = r.shape
+        s = torch.sum(r[:-1] * r[1:], dim=0)                                  # (n,)
+        ds = torch.zeros_like(r)                                              # d s / d r_a
+        ds[:-1] += r[1:]
+        ds[1:] += r[:-1]
+        V = 0.5 * torch.sum(w2 * r * r, dim=0) + self.lam * s * s
+        grad = w2 * r + 2.0 * self.lam * s * ds
+        hess = torch.zeros((d, d, n), dtype=r.dtype, device=r.device)
+        idx = torch.arange(d, device=r.device)
+        hess[idx, idx] = w2.expand(-1, n).clone()
+        hess += 2.0 * self.lam * ds.unsqueeze(1) * ds.unsqueeze(0)
+        off = 2.0 * self.lam * s
+        hess[idx[:-1], idx[1:]] += off
+        hess[idx[1:], idx[:-1]] += off
+        return V, grad, hess
+
+    def derivative_coupling_1st(self, r):
+        return self.nac.to(r.device).unsqueeze(1).expand(-1, r.shape[1])
+
+    def derivative_coupling_2nd(self, r):
+        return torch.zeros_like(r)
+
+
+@pytest.mark.parametrize("kind", ["HK", "WM"])
+def test_generic_python_potential_matches_oracle(kind):
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import propagators as PR
+    rng = np.random.default_rng(21)
+    D, n, nt, dt = 5, 160, 15, 1.5
+    omega = torch.from_numpy(np.sort(rng.uniform(700, 2600, D)) / 219474.63)
+    masses = torch.from_numpy(rng.uniform(0.8, 1.6, D))
+    nac = torch.from_numpy(rng.normal(0, 1e-3, D))
+    pot = CoupledQuarticPotential(omega, 2.0e-6, masses, nac)
+    q0 = torch.from_numpy(rng.uniform(-6.0, 6.0, D))
+    p0 = 0.0 * q0
+    G = torch.diag(omega * masses)
+    E0 = float(0.5 * omega.sum())
+    if kind == "HK":
+        ref, prop = orc.HKOracle(G, G), PR.HermanKlukPropagator(G, G, device="cuda")
+    else:
+        ref, prop = orc.WMOracle(G, G, 80.0, 80.0), PR.WaltonManolopoulosPropagator(G, G, 80.0, 80.0, device="cuda")
+    torch.manual_seed(9)
+    ref.initial_conditions(q0, p0, G, ntraj=n)
+    rc, rk = orc.run_loop(ref, pot, dt, nt, E0)
+    prop.set_initial_conditions(q0, p0, G, ref.zi, ref.probi)
+    c, k = prop.run(pot, dt, nt, E0)
+    assert np.abs(rc[-1] - rc[0]) > 1e-3                     # the dynamics is not trivial
+    assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-9
+    y_ref = ref.y.numpy()
+    assert cases.rel_err(prop.y.cpu().numpy(), y_ref) < 1e-9
