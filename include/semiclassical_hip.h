@@ -226,10 +226,13 @@ int sc_stage_consume(const sc_state *st, const sc_dense_scratch *sc, const doubl
 int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const sc_dense_scratch *sc, double dt, int32_t stage,
                   double *energy_partials, void *stream);
 
-/* RK4 of the four monodromy blocks with the four stage Hessians hess[n][4][D][D], then the HK prefactor (diagonal or
- * dense/rank-deficient width matrices) and its branch tracking; D <= 64.  mode as in sc_hk_step. */
+/* RK4 of the four monodromy blocks with the four stage Hessians hess[n][4][D][D] (each used as A[i][k] = hess[k][i];
+ * the built-in potentials produce symmetric images) on the FP64 matrix cores, then the HK prefactor (diagonal or
+ * dense/rank-deficient width matrices) and its branch tracking; D <= 96.  For D > 64 the RK4 sums do not fit the
+ * register file: mono_sums [n][4][D][D] is their scratch (may be NULL for D <= 64).  mode: 0 = step + prefactor,
+ * 1 = prefactor and tracker initialisation only. */
 int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
-                       double dt, int32_t mode, void *stream);
+                       double *mono_sums, double dt, int32_t mode, void *stream);
 
 /* Structure-exploiting HK step ("separable shortcut"): same contract as sc_hk_step for a
  * separable potential (SC_POT_MORSE / _HARMONIC_SEP / _EPS_MORSE), diagonal width matrices (hk->diag) and monodromy

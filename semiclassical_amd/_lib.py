@@ -99,8 +99,8 @@ SIGNATURES = {
     "sc_stage_point": (C.c_int, [P(sc_state), P(sc_dense_scratch), C.c_double, C.c_int32, c_double_p, C.c_void_p]),
     "sc_stage_consume": (C.c_int, [P(sc_state), P(sc_dense_scratch), c_double_p, c_double_p, c_double_p, C.c_double,
                                    C.c_int32, c_double_p, C.c_void_p]),
-    "sc_dense_mono_step": (C.c_int, [P(sc_state), P(sc_hk_consts), c_double_p, c_double_p, C.c_double, C.c_int32,
-                                     C.c_void_p]),
+    "sc_dense_mono_step": (C.c_int, [P(sc_state), P(sc_hk_consts), c_double_p, c_double_p, c_double_p, C.c_double,
+                                     C.c_int32, C.c_void_p]),
     "sc_pair_sum_tiles": (C.c_int64, [C.c_int64]),
     "sc_pair_sum": (C.c_int, [c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p,
                               c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, c_double_p, C.c_void_p]),

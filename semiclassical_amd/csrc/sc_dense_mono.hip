@@ -29,6 +29,8 @@ struct MonoArgs {
     const double *hess;         // [n][4][D][D] stage Hessians, or [D][D] when hess_stride == 0 (constant Hessian)
     int64_t hess_stride;        // doubles between the Hessian blocks of consecutive trajectories (4 D D or 0)
     int64_t stage_stride;       // doubles between consecutive stages (D D or 0)
+    double *msum;               // [n][4][D][D] RK4 sums of the monodromy blocks (only the D > 64 kernel)
+    int panel;                  // columns of M R formed at a time in the prefactor kernel (LDS budget)
     double dt;
     int mode;                   // 0: after a step, 1: tracker initialisation (prefactor kernel only)
 };
@@ -155,6 +157,97 @@ __global__ __launch_bounds__(128 * NT, 1) void dense_mono_mfma_kernel(MonoArgs A
     }
 }
 
+// The same RK4 for 64 < D <= 96 (NT = 5, 6).  The register file of one CU no longer holds the whole step: a workgroup
+// has NT wavefronts (one 16-column tile each) and does the two plane pairs one after the other; X0 / Y0 are re-read
+// from the (still unmodified) state at every stage and the RK4 sums live in a global scratch of the size of the
+// state (A.msum), so only the stage matrices and the accumulators stay in registers.  One Hessian image in LDS
+// (rows padded to 112 doubles), staged per stage and pair.
+#define HSB 112
+template <int NT, int KT>
+__global__ __launch_bounds__(64 * NT, 1) void dense_mono_mfma_big_kernel(MonoArgs A) {
+    extern __shared__ double2 smem2[];           // Hessian image [16 NT][HSB], 1/m [128]
+    constexpr int HB = 16 * NT * HSB;
+    double *Hs0 = (double *)smem2, *wm = Hs0 + HB;
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x, nth = 64 * NT;
+    const int lane = tid & 63, jt = tid >> 6;
+    const int col = 16 * jt + (lane & 15), rg = lane >> 4;
+    const bool colok = col < D;
+    const unsigned toff = (unsigned)(rg * D + col);
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    for (int i = tid; i < 128; i += nth) wm[i] = i < D ? A.inv_mass[i] : 0.0;
+    for (int e = tid; e < HB; e += nth) Hs0[e] = 0.0;
+    __syncthreads();
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        const double *Hg = A.hess + tr * A.hess_stride;
+#pragma unroll 1
+        for (int pair = 0; pair < 2; ++pair) {
+            double *Mx = A.st.mono + tr * 4 * (int64_t)DD + (int64_t)pair * DD, *My = Mx + 2 * (int64_t)DD;
+            double *Sx = A.msum + tr * 4 * (int64_t)DD + (int64_t)pair * DD, *Sy = Sx + 2 * (int64_t)DD;
+            double Xs[NT][4], Ys[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = colok && 16 * t + rg + 4 * r < D;
+                    Xs[t][r] = ok ? (Mx + (16 * t + 4 * r) * D)[toff] : 0.0;
+                    Ys[t][r] = ok ? (My + (16 * t + 4 * r) * D)[toff] : 0.0;
+                }
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                __syncthreads();                         // everybody is done with the previous image
+                const double *Hst = Hg + st * A.stage_stride;
+                for (int e = tid; e < DD; e += nth) Hs0[(e / D) * HSB + (e % D)] = Hst[e];
+                __syncthreads();
+                d4 acc[NT];
+#pragma unroll
+                for (int I = 0; I < NT; ++I) acc[I] = (d4){0.0, 0.0, 0.0, 0.0};
+                const double *arow = Hs0 + rg * HSB + (lane & 15);
+                double a_cur[NT], a_nxt[NT];
+#pragma unroll
+                for (int I = 0; I < NT; ++I) a_cur[I] = arow[16 * I];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    if (kt + 1 < KT) {
+#pragma unroll
+                        for (int I = 0; I < NT; ++I) a_nxt[I] = arow[4 * (kt + 1) * HSB + 16 * I];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double b = Xs[kt >> 2][kt & 3];
+#pragma unroll
+                    for (int I = 0; I < NT; ++I)
+                        acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[I], b, acc[I], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) a_cur[I] = a_nxt[I];
+                }
+                const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = colok && 16 * t + rg + 4 * r < D;
+                        if (ok) {
+                            const size_t off = (size_t)(16 * t + 4 * r) * D + toff;
+                            const double kx = wm[16 * t + rg + 4 * r] * Ys[t][r], ky = -acc[t][r];
+                            const double x0 = Mx[off], y0 = My[off];
+                            const double sx = (st == 0 ? 0.0 : Sx[off]) + wgt * kx, sy = (st == 0 ? 0.0 : Sy[off]) + wgt * ky;
+                            if (st < 3) {
+                                Sx[off] = sx; Sy[off] = sy;
+                                Xs[t][r] = fma(c, kx, x0);
+                                Ys[t][r] = fma(c, ky, y0);
+                            } else {
+                                Mx[off] = fma(h6, sx, x0);
+                                My[off] = fma(h6, sy, y0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // prefactor matrix, determinant and branch tracker from the monodromy blocks in global memory
 __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
     extern __shared__ double2 smem2[];
@@ -173,7 +266,7 @@ __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
             }
             __syncthreads();
         } else {
-            general_prefactor_matrix(A.hk, M, M + DD, M + 2 * DD, M + 3 * DD, D, X, mat);
+            general_prefactor_matrix(A.hk, M, M + DD, M + 2 * DD, M + 3 * DD, D, X, mat, A.panel);
         }
         const cplx det = lds_lu_det(mat, dp, &ipiv);
         if (tid == 0) {
@@ -272,50 +365,59 @@ extern "C" int sc_stage_consume(const sc_state *st, const sc_dense_scratch *sc, 
 }
 
 extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
-                                  double dt, int32_t mode, void *stream) {
+                                  double *mono_sums, double dt, int32_t mode, void *stream) {
     if (!st || !hk || (mode == 0 && (!inv_mass || !hess)))
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: null argument");
     const int D = st->dim;
-    if (D < 1 || D > 64) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d outside 1..64", D);
+    if (D < 1 || D > 96) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d outside 1..96", D);
+    if (D > 64 && mode == 0 && !mono_sums)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: D=%d > 64 needs the mono_sums scratch", D);
     if (hk->dim != D || hk->dprime < 1 || hk->dprime > D)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: bad prefactor constants");
     if (st->n <= 0) return SC_OK;
     hipStream_t s = (hipStream_t)stream;
-    MonoArgs a{*st, *hk, inv_mass, hess, 4 * (int64_t)D * D, (int64_t)D * D, dt, mode};
+    // prefactor kernel: d' x d' matrix + a panel of X = M R in LDS
+    const size_t dp = hk->dprime, budget = 150 * 1024;
+    int panel = (int)dp;
+    if (!hk->diag) while (panel > 8 && (dp * dp + (size_t)D * panel) * 16 + 32 > budget) panel = (panel + 1) / 2;
+    const size_t lds = (dp * dp + (hk->diag ? 0 : (size_t)D * panel)) * 16 + 32;
+    if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: needs %zu B of LDS", lds);
+    MonoArgs a{*st, *hk, inv_mass, hess, 4 * (int64_t)D * D, (int64_t)D * D, mono_sums, panel, dt, mode};
     if (mode == 0) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
         const int nt = (D + 15) / 16;
-        const size_t rk4_lds = ((size_t)2 * 16 * nt * HS + 64 + (size_t)2 * nt * (nt < 4 ? 2 : 1) * 4 * nt * 64) * sizeof(double);
-#define SC_LAUNCH_MONO(NT_, KT_, WGS_)                                                                              \
+        const size_t rk4_lds = nt <= 4 ? ((size_t)2 * 16 * nt * HS + 64 + (size_t)2 * nt * (nt < 4 ? 2 : 1) * 4 * nt * 64) * sizeof(double)
+                                       : ((size_t)16 * nt * HSB + 128) * sizeof(double);
+#define SC_LAUNCH_MONO(KERNEL_, NT_, KT_, WGS_, THREADS_)                                                          \
         do {                                                                                                        \
-            if (hipFuncSetAttribute((const void *)dense_mono_mfma_kernel<NT_, KT_>,                                 \
+            if (hipFuncSetAttribute((const void *)KERNEL_<NT_, KT_>,                                                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk4_lds) != hipSuccess)        \
                 return sc_check_launch("sc_dense_mono_step (LDS attribute)");                                       \
             const int64_t g_ = (int64_t)cus * (WGS_);                                                               \
-            hipLaunchKernelGGL((dense_mono_mfma_kernel<NT_, KT_>), dim3((unsigned)(st->n < g_ ? st->n : g_)),       \
-                               dim3(128 * NT_), rk4_lds, s, a);                                                     \
+            hipLaunchKernelGGL((KERNEL_<NT_, KT_>), dim3((unsigned)(st->n < g_ ? st->n : g_)),                      \
+                               dim3(THREADS_), rk4_lds, s, a);                                                      \
         } while (0)
-#define SC_MONO_CASES(NT_, WGS_)                                                                                    \
-        case 4 * NT_ - 3: SC_LAUNCH_MONO(NT_, 4 * NT_ - 3, WGS_); break;                                            \
-        case 4 * NT_ - 2: SC_LAUNCH_MONO(NT_, 4 * NT_ - 2, WGS_); break;                                            \
-        case 4 * NT_ - 1: SC_LAUNCH_MONO(NT_, 4 * NT_ - 1, WGS_); break;                                            \
-        case 4 * NT_: SC_LAUNCH_MONO(NT_, 4 * NT_, WGS_); break;
+#define SC_MONO_CASES(KERNEL_, NT_, WGS_, THREADS_)                                                                 \
+        case 4 * NT_ - 3: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_ - 3, WGS_, THREADS_); break;                         \
+        case 4 * NT_ - 2: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_ - 2, WGS_, THREADS_); break;                         \
+        case 4 * NT_ - 1: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_ - 1, WGS_, THREADS_); break;                         \
+        case 4 * NT_: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_, WGS_, THREADS_); break;
         switch ((D + 3) / 4) {
-            SC_MONO_CASES(1, 8)
-            SC_MONO_CASES(2, 4)
-            SC_MONO_CASES(3, 1)
-            SC_MONO_CASES(4, 1)
+            SC_MONO_CASES(dense_mono_mfma_kernel, 1, 8, 128)
+            SC_MONO_CASES(dense_mono_mfma_kernel, 2, 4, 256)
+            SC_MONO_CASES(dense_mono_mfma_kernel, 3, 1, 384)
+            SC_MONO_CASES(dense_mono_mfma_kernel, 4, 1, 512)
+            SC_MONO_CASES(dense_mono_mfma_big_kernel, 5, 1, 320)
+            SC_MONO_CASES(dense_mono_mfma_big_kernel, 6, 1, 384)
         }
 #undef SC_MONO_CASES
 #undef SC_LAUNCH_MONO
         const int rc = sc_check_launch("sc_dense_mono_step (RK4)");
         if (rc) return rc;
     }
-    const size_t lds = ((size_t)hk->dprime * hk->dprime + (hk->diag ? 0 : (size_t)D * hk->dprime)) * 16 + 32;
-    if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: needs %zu B of LDS", lds);
     if (hipFuncSetAttribute((const void *)dense_prefactor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sc_check_launch("sc_dense_mono_step (LDS attribute)");
     hipLaunchKernelGGL(dense_prefactor_kernel, dim3(sc_dense_grid(st->n)), dim3(256), lds, s, a);

@@ -181,7 +181,10 @@ class HermanKlukPropagator(object):
 
     def _prefactor_initial(self):
         """prefactor at t = 0 and initialisation of the branch tracker (reference propagators.py:631)"""
-        check(lib.sc_hk_step(_NULL_POT(self.dim), self._state, self._hk, 0.0, 1, None, self._stream()))
+        if self.dim > 64:
+            check(lib.sc_dense_mono_step(self._state, self._hk, None, None, None, 0.0, 1, self._stream()))
+        else:
+            check(lib.sc_hk_step(_NULL_POT(self.dim), self._state, self._hk, 0.0, 1, None, self._stream()))
         self._after_prefactor(track=2)
 
     # ------------------------------------------------------------------ time stepping
@@ -201,7 +204,8 @@ class HermanKlukPropagator(object):
         if hasattr(potential, "_gdml_model"):
             self._sync_dense_mono(leave_diagonal=True)
             nblocks = self._launch_dense_step(potential, dt, s)
-        elif not hasattr(potential, "_descriptor"):
+        elif not hasattr(potential, "_descriptor") or self.dim > 64:
+            # no device descriptor, or beyond the fused kernels' D <= 64: the potential's own torch code + dense path
             self._sync_dense_mono(leave_diagonal=True)
             nblocks = self._launch_generic_step(potential, dt, s)
         else:
@@ -241,7 +245,8 @@ class HermanKlukPropagator(object):
             model = potential._gdml_model(self.device)
         for stage in range(4):
             check(lib.sc_gdml_stage(model, self._state, self._dense, dt, stage, ptr(self._epart), s))
-        check(lib.sc_dense_mono_step(self._state, self._hk, model.inv_mass, ptr(self._dense_bufs[0]), dt, 0, s))
+        check(lib.sc_dense_mono_step(self._state, self._hk, model.inv_mass, ptr(self._dense_bufs[0]), self._mono_sums_ptr(),
+                                     dt, 0, s))
         return self._gdense
 
     def _dense_scratch(self):
@@ -257,6 +262,14 @@ class HermanKlukPropagator(object):
             if self._gdense > self._epart.numel():
                 self._epart = torch.zeros(self._gdense, dtype=F64, device=dev)
         return self._dense
+
+    def _mono_sums_ptr(self):
+        """scratch for the RK4 sums of the monodromy blocks, only needed beyond D = 64 (sc_dense_mono_step)"""
+        if self.dim <= 64:
+            return None
+        if getattr(self, "_mono_sums", None) is None or self._mono_sums.shape != self._mono.shape:
+            self._mono_sums = torch.empty_like(self._mono)
+        return ptr(self._mono_sums)
 
     def _launch_generic_step(self, potential, dt, s):
         """Any object with the reference's potential protocol (potentials.py:41-204: ``harmonic_approximation(r) ->
@@ -282,7 +295,8 @@ class HermanKlukPropagator(object):
             self._dense_bufs[0][:, stage].copy_(hess.permute(2, 1, 0))
             check(lib.sc_stage_consume(self._state, dense, ptr(inv_mass), ptr(Vc), ptr(gt), dt, stage,
                                        ptr(self._epart), s))
-        check(lib.sc_dense_mono_step(self._state, self._hk, ptr(inv_mass), ptr(self._dense_bufs[0]), dt, 0, s))
+        check(lib.sc_dense_mono_step(self._state, self._hk, ptr(inv_mass), ptr(self._dense_bufs[0]), self._mono_sums_ptr(),
+                                     dt, 0, s))
         return self._gdense
 
     def _after_prefactor(self, track):

@@ -22,7 +22,7 @@ def torch_reference(M, H, inv_mass, dt):
     return M + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
 
 
-@pytest.mark.parametrize("D", [3, 12, 16, 17, 30, 33, 45, 48, 51, 57, 61, 64])
+@pytest.mark.parametrize("D", [3, 12, 16, 17, 30, 33, 45, 48, 51, 57, 61, 64, 65, 70, 80, 81, 90, 96])
 def test_dense_mono_step_matches_torch(D):
     from semiclassical_amd import hostmath
     from semiclassical_amd._lib import lib, check, ptr, sc_state, sc_hk_consts
@@ -51,7 +51,8 @@ def test_dense_mono_step_matches_torch(D):
     state = sc_state(n=n, dim=D, qp=ptr(qp), act=ptr(act), mono=ptr(Md), c2=ptr(c2), sgn=ptr(sgn))
     hk = sc_hk_consts(dim=D, dprime=D, diag=1, st=ptr(std), si=ptr(sid))
     stream = torch.cuda.current_stream().cuda_stream
-    check(lib.sc_dense_mono_step(state, hk, ptr(wd), ptr(Hd), dt, 0, stream))
+    sums = torch.empty_like(Md) if D > 64 else None
+    check(lib.sc_dense_mono_step(state, hk, ptr(wd), ptr(Hd), ptr(sums) if D > 64 else None, dt, 0, stream))
     torch.cuda.synchronize()
     got = Md.cpu()
     assert float((got - want).abs().max() / want.abs().max()) < 1e-13

@@ -75,3 +75,36 @@ def test_generic_python_potential_matches_oracle(kind):
     assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-9
     y_ref = ref.y.numpy()
     assert cases.rel_err(prop.y.cpu().numpy(), y_ref) < 1e-9
+
+
+@pytest.mark.parametrize("dense_gamma", [False, True])
+def test_more_than_64_dimensions_through_the_dense_path(dense_gamma):
+    """D = 70 > 64: beyond the fused kernels every potential takes the dense path (its own torch code at the stage
+    points, MFMA monodromy kernel for 64 < D <= 96 with the RK4 sums in a global scratch, panelised prefactor);
+    anharmonic AS (Morse) model with diagonal or rotated width matrices against the CPU oracle"""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    rng = np.random.default_rng(70)
+    D, n, nt, dt = 70, 24, 4, 2.0
+    omega = torch.from_numpy(np.sort(rng.uniform(400, 3200, D)) / 219474.63)
+    S = torch.from_numpy(rng.uniform(0.01, 0.1, D) * rng.choice([-1, 1], D))
+    nac = torch.from_numpy(rng.normal(0, 1e-4, D))
+    chi = torch.full((D,), 0.02)
+    q0 = torch.sqrt(2 * abs(S) / omega) * torch.sign(S)
+    p0 = 0.0 * q0
+    if dense_gamma:
+        Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        G = torch.from_numpy(Q @ np.diag(omega.numpy() * rng.uniform(0.8, 1.25, D)) @ Q.T)
+        G = 0.5 * (G + G.T)
+    else:
+        G = torch.diag(omega)
+    E0 = float(0.5 * omega.sum())
+    ref = orc.HKOracle(G, G)
+    torch.manual_seed(2)
+    ref.initial_conditions(q0, p0, G, ntraj=n)
+    rc, rk = orc.run_loop(ref, orc.MorseOracle(omega, chi.clone(), nac), dt, nt, E0)
+    prop = PR.HermanKlukPropagator(G, G, device="cuda")
+    prop.set_initial_conditions(q0, p0, G, ref.zi, ref.probi)
+    c, k = prop.run(P.MorsePotential(omega, chi.clone(), nac), dt, nt, E0)
+    assert cases.rel_err(prop.y.cpu().numpy(), ref.y.numpy()) < 1e-9
+    assert cases.rel_err(c, rc) < 1e-8 and cases.rel_err(k, rk) < 1e-8
