@@ -228,17 +228,19 @@ __global__ __launch_bounds__(64 * NT, 1) void dense_mono_mfma_big_kernel(MonoArg
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = colok && 16 * t + rg + 4 * r < D;
                         if (ok) {
-                            const size_t off = (size_t)(16 * t + 4 * r) * D + toff;
+                            // wave-uniform row bases + one per-thread 32-bit offset (no hoisted 64-bit offsets)
+                            const int rowoff = (16 * t + 4 * r) * D;
+                            double *mx = Mx + rowoff, *my = My + rowoff, *sxp = Sx + rowoff, *syp = Sy + rowoff;
                             const double kx = wm[16 * t + rg + 4 * r] * Ys[t][r], ky = -acc[t][r];
-                            const double x0 = Mx[off], y0 = My[off];
-                            const double sx = (st == 0 ? 0.0 : Sx[off]) + wgt * kx, sy = (st == 0 ? 0.0 : Sy[off]) + wgt * ky;
+                            const double x0 = mx[toff], y0 = my[toff];
+                            const double sx = (st == 0 ? 0.0 : sxp[toff]) + wgt * kx, sy = (st == 0 ? 0.0 : syp[toff]) + wgt * ky;
                             if (st < 3) {
-                                Sx[off] = sx; Sy[off] = sy;
+                                sxp[toff] = sx; syp[toff] = sy;
                                 Xs[t][r] = fma(c, kx, x0);
                                 Ys[t][r] = fma(c, ky, y0);
                             } else {
-                                Mx[off] = fma(h6, sx, x0);
-                                My[off] = fma(h6, sy, y0);
+                                mx[toff] = fma(h6, sx, x0);
+                                my[toff] = fma(h6, sy, y0);
                             }
                         }
                     }

@@ -38,6 +38,7 @@ struct GdmlLds {
 };
 
 #define GDML_CHUNK 16
+#define GDML_NB 2            // atom-pair blocks of the Hessian per thread and group
 
 __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt) {
     GdmlLds L;
@@ -114,7 +115,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     __syncthreads();
     // ---- gradient in descriptor space, then Cartesian gradient
     // every wavefront takes a slice of the training points (lanes over the descriptor: coalesced rows), the per-wave
-    // partial sums meet in LDS (L.XJ is free at this point; nw * Dd <= GDML_CHUNK * 3N is checked by the host)
+    // partial sums meet in LDS (L.xsL, GDML_CHUNK * Dd doubles, is free at this point and holds nw <= 16 rows)
     for (int d0 = 0; d0 < Dd; d0 += 64) {
         const int d = d0 + lane;
         double g = 0.0;
@@ -122,13 +123,13 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
             const double xv = L.x[d];
             for (int m = wave; m < Mt; m += nw)
                 g += L.fm[m] * G.jx_alphas[(size_t)m * Dd + d] - L.ea[m] * (xv - G.xs_train[(size_t)m * Dd + d]);
-            L.XJ[wave * Dd + d] = g;
+            L.xsL[wave * Dd + d] = g;
         }
     }
     __syncthreads();
     for (int d = tid; d < Dd; d += nth) {
         double g = 0.0;
-        for (int w = 0; w < nw; ++w) g += L.XJ[w * Dd + d];
+        for (int w = 0; w < nw; ++w) g += L.xsL[w * Dd + d];
         L.gx[d] = g;
     }
     __syncthreads();
@@ -143,19 +144,75 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         }
         L.grad[xi] = g * G.std;
     }
-    // ---- Hessian by atom-pair blocks (a <= b); a thread may own several blocks
+    // ---- Hessian by atom-pair blocks (a <= b).  A thread owns up to GDML_NB blocks of a group, so that the chunk
+    // products J^T xd_m, J^T A_m are formed once per group of GDML_NB * blockDim blocks (once in all for N <= 31).
     const int nblk = N * (N + 1) / 2;
-    for (int blk0 = 0; blk0 < nblk; blk0 += nth) {
-        const int blk = blk0 + tid;
-        int a = 0, b = 0;
-        const bool own = blk < nblk;
-        if (own) {   // blk = b (b+1)/2 + a with a <= b
-            b = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
-            while (b * (b + 1) / 2 > blk) --b;
-            while ((b + 1) * (b + 2) / 2 <= blk) ++b;
-            a = blk - b * (b + 1) / 2;
+    auto finish_block = [&](double (&h)[3][3], int a, int b) {
+        // - S J^T J + second derivatives of the descriptor
+        if (a != b) {
+            const int d = pair_index(a, b);          // b > a: b is the "k" atom of the pair
+            const double x = L.x[d], g = L.gx[d];
+            const double jx = L.jd[3 * d], jy = L.jd[3 * d + 1], jz = L.jd[3 * d + 2];
+            const double jv[3] = {jx, jy, jz};
+            // diff = r_k - r_l = -jd / x^3
+            const double ix3 = -1.0 / (x * x * x);
+            const double df[3] = {jx * ix3, jy * ix3, jz * ix3};
+            const double x5 = x * x * x * x * x, x3 = x * x * x;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
+                    h[u][v] += S * jv[u] * jv[v] - T;          // J^T J block is -jd jd^T
+                }
+        } else {
+            for (int c = 0; c < N; ++c) {
+                if (c == a) continue;
+                const int d = pair_index(a, c);
+                const double x = L.x[d], g = L.gx[d];
+                const double jv[3] = {L.jd[3 * d], L.jd[3 * d + 1], L.jd[3 * d + 2]};
+                const double ix3 = -1.0 / (x * x * x);
+                const double df[3] = {jv[0] * ix3, jv[1] * ix3, jv[2] * ix3};
+                const double x5 = x * x * x * x * x, x3 = x * x * x;
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
+                        h[u][v] += -S * jv[u] * jv[v] + T;
+                    }
+            }
         }
-        double h[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const double val = h[u][v] * G.std;
+                hess[(size_t)(3 * a + u) * X + 3 * b + v] = val;
+                hess[(size_t)(3 * b + v) * X + 3 * a + u] = val;
+            }
+    };
+    for (int blk0 = 0; blk0 < nblk; blk0 += GDML_NB * nth) {
+        int ba[GDML_NB], bb[GDML_NB];
+        bool own[GDML_NB];
+        double h[GDML_NB][3][3];
+#pragma unroll
+        for (int sl = 0; sl < GDML_NB; ++sl) {
+            const int blk = blk0 + sl * nth + tid;
+            own[sl] = blk < nblk;
+            int a = 0, b = 0;
+            if (own[sl]) {   // blk = b (b+1)/2 + a with a <= b
+                b = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+                while (b * (b + 1) / 2 > blk) --b;
+                while ((b + 1) * (b + 2) / 2 <= blk) ++b;
+                a = blk - b * (b + 1) / 2;
+            }
+            ba[sl] = a; bb[sl] = b;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) h[sl][u][v] = 0.0;
+        }
         for (int m0 = 0; m0 < Mt; m0 += GDML_CHUNK) {
             const int mc = min(GDML_CHUNK, Mt - m0);
             __syncthreads();
@@ -200,7 +257,10 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                 }
             }
             __syncthreads();
-            if (own) {
+#pragma unroll
+            for (int sl = 0; sl < GDML_NB; ++sl) {
+                if (!own[sl]) continue;
+                const int a = ba[sl], b = bb[sl];
                 for (int mm = 0; mm < mc; ++mm) {
                     const double w = L.wm[m0 + mm], e = L.em[m0 + mm];
                     const double *xj = L.XJ + mm * X, *aj = L.AJ + mm * X;
@@ -210,57 +270,15 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
 #pragma unroll
                         for (int v = 0; v < 3; ++v) {
                             const double xb = xj[3 * b + v], ab = aj[3 * b + v];
-                            h[u][v] += w * xa * xb - e * (aa * xb + xa * ab);
+                            h[sl][u][v] += w * xa * xb - e * (aa * xb + xa * ab);
                         }
                     }
                 }
             }
         }
-        if (own) {
-            // - S J^T J + second derivatives of the descriptor
-            if (a != b) {
-                const int d = pair_index(a, b);          // b > a: b is the "k" atom of the pair
-                const double x = L.x[d], g = L.gx[d];
-                const double jx = L.jd[3 * d], jy = L.jd[3 * d + 1], jz = L.jd[3 * d + 2];
-                const double jv[3] = {jx, jy, jz};
-                // diff = r_k - r_l = -jd / x^3
-                const double ix3 = -1.0 / (x * x * x);
-                const double df[3] = {jx * ix3, jy * ix3, jz * ix3};
-                const double x5 = x * x * x * x * x, x3 = x * x * x;
 #pragma unroll
-                for (int u = 0; u < 3; ++u)
-#pragma unroll
-                    for (int v = 0; v < 3; ++v) {
-                        const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
-                        h[u][v] += S * jv[u] * jv[v] - T;          // J^T J block is -jd jd^T
-                    }
-            } else {
-                for (int c = 0; c < N; ++c) {
-                    if (c == a) continue;
-                    const int d = pair_index(a, c);
-                    const double x = L.x[d], g = L.gx[d];
-                    const double jv[3] = {L.jd[3 * d], L.jd[3 * d + 1], L.jd[3 * d + 2]};
-                    const double ix3 = -1.0 / (x * x * x);
-                    const double df[3] = {jv[0] * ix3, jv[1] * ix3, jv[2] * ix3};
-                    const double x5 = x * x * x * x * x, x3 = x * x * x;
-#pragma unroll
-                    for (int u = 0; u < 3; ++u)
-#pragma unroll
-                        for (int v = 0; v < 3; ++v) {
-                            const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
-                            h[u][v] += -S * jv[u] * jv[v] + T;
-                        }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-#pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    const double val = h[u][v] * G.std;
-                    hess[(size_t)(3 * a + u) * X + 3 * b + v] = val;
-                    hess[(size_t)(3 * b + v) * X + 3 * a + u] = val;
-                }
-        }
+        for (int sl = 0; sl < GDML_NB; ++sl)
+            if (own[sl]) finish_block(h[sl], ba[sl], bb[sl]);
     }
     __syncthreads();
     return energy;
@@ -343,8 +361,6 @@ int check_model(const sc_gdml_model *g, const char *who) {
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: descriptor size %d does not match %d atoms", who, g->n_desc, g->n_atoms);
     if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8 > 160 * 1024)
         return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d, M=%d) needs more than 160 KiB of LDS", who, g->n_atoms, g->n_train);
-    if (4 * g->n_desc > GDML_CHUNK * 3 * g->n_atoms)      // per-wave partial sums of the descriptor gradient live in L.XJ
-        return sc_fail(SC_ERR_UNSUPPORTED, "%s: N=%d atoms exceed the staging buffers", who, g->n_atoms);
     return SC_OK;
 }
 

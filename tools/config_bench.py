@@ -45,6 +45,43 @@ def run(name, label):
           f"({wall / steps * 1e3:.3f} ms/step)  |C(0)|={abs(c[0]):.4f}", flush=True)
 
 
+def run_gdml30(n, steps):
+    """config 5 at its stated size: a synthetic 30-atom sGDML model (no such model ships with the reference), D = 90"""
+    from tests.test_gdml_gpu import synthetic_model
+    from oracle import sc_oracle as orc
+    from semiclassical_amd.gdml import MolecularGDMLPotential
+    N = 30
+    model, pos = synthetic_model(N, 200, 30)
+    g0 = orc.GDMLOracle(model).forward(torch.from_numpy(pos.reshape(1, -1)))[1]
+    model["R_d_desc_alpha"] = model["R_d_desc_alpha"] * (0.02 / float(g0.abs().max()))
+    masses = np.repeat(np.full(N, 12.0 * 1822.888), 3)
+
+    class _Fchk(object):
+        def nonadiabatic_coupling(self_):
+            return np.zeros(3 * N)
+
+        def masses(self_):
+            return masses
+
+        def atomic_numbers(self_):
+            return model["z"]
+    pot = MolecularGDMLPotential(model, _Fchk())
+    q0 = torch.from_numpy(pos.reshape(-1))
+    G = torch.diag(torch.full((3 * N,), 40.0))
+    prop = PR.HermanKlukPropagator(G, G, device="cuda")
+    prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(7))
+    prop.run(pot, 2.0, 2, 0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    c, k = prop.run(pot, 2.0, steps, 0.0)
+    wall = time.perf_counter() - t0
+    print(f"config 5  HK  synthetic 30-atom sGDML (M=200): D=90 n={n} steps={steps}  {n * steps / wall:.3e} "
+          f"trajectory-steps/s  ({wall / steps * 1e3:.3f} ms/step)", flush=True)
+
+
+if os.environ.get("GDML30"):
+    run_gdml30(int(sys.argv[1]) if len(sys.argv) > 1 else 10000, int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+    sys.exit(0)
 if os.environ.get("GDML_ONLY"):
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     run("hk_coumarin_gdml", "config 5* HK  coumarin sGDML (17 atoms, M=200)")
