@@ -19,7 +19,6 @@ batched complex ``det`` -- so that its wall time is a fair stand-in for the
 reference's CPU path.  All citations are relative to
 ``/root/reference``.
 """
-import math
 
 import numpy as np
 import torch

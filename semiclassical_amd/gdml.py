@@ -9,7 +9,6 @@ field in this package.
 import numpy as np
 import torch
 
-from . import _lib
 from ._lib import lib, check, ptr, sc_gdml_model
 from .potentials import _MolecularPotentialBase
 

@@ -18,7 +18,6 @@ Differences a caller can observe:
     correlate, step -- nt times) without any host synchronisation.
 """
 import logging
-import math
 
 import numpy as np
 import torch
