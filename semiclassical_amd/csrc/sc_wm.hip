@@ -91,6 +91,17 @@ __device__ __forceinline__ double track_sign(int track, cplx z, cplx *prev, doub
     return s;
 }
 
+// sizes of the shared LDS regions of wm_kernel (doubles / complex values), see the carve-up there
+__host__ __device__ inline size_t wm_region_p(int D, int dp) {
+    const size_t E = 2 * (size_t)dp, a = 3 * (size_t)D * E + E * E, b = 2 * (size_t)D * D + 4 * (size_t)dp * dp + 20 * (size_t)dp;
+    const size_t m = a > b ? a : b;
+    return m + (m & 1);
+}
+__host__ __device__ inline size_t wm_region_q(int D, int dp) {
+    const size_t E = 2 * (size_t)dp, a = 2 * E * E, b = 2 * (size_t)D * D;
+    return a > b ? a : b;
+}
+
 __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     extern __shared__ double2 smem2[];
     __shared__ double red[32];
@@ -98,28 +109,25 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     const int D = A.st.dim, dp = A.wc.dprime, E = 2 * dp, DD = D * D, tid = threadIdx.x, nth = blockDim.x;
     const sc_wm_consts &W = A.wc;
 
-    // ---- LDS carve-up ----
+    // ---- LDS carve-up.  Arrays whose lifetimes do not overlap share storage (a trajectory then needs ~14 KB instead of
+    // ~26 KB at D = 12, d' = 6, which is what limits the number of resident trajectories per CU):
+    //   region P: {Mq', Mp', Gamma_t Mq', Mp'^T Mq'} (dead once A' and BQ' exist) -> Wm = BQ' iA' (dead once Gt, Gti
+    //             exist) -> {V, [M'|I], hat, rho}
+    //   region Q: [A'/s | I] (dead once Wm exists) -> {Gt (later CQQ), Gti}
     double *f = (double *)smem2;
-    double *Mq = f;              f += D * E;        // Mq' (D x E)
-    double *Mp = f;              f += D * E;        // Mp'
-    double *Tq = f;              f += D * E;        // Gamma_t Mq'
-    double *G = f;               f += E * E;        // Mp'^T Mq'
     double *vec = f;             f += 8 * D;        // dq, dQ, dp, g, s_dq, w_dQ, (2 spare)
-    f += ((f - (double *)smem2) & 1);               // 16-byte alignment of the complex arrays
+    double *rowtmp = f;          f += 3 * D + (D & 1);   // per-row partial results of the scalar tail (3 x D)
+    double *P = f;               f += wm_region_p(D, dp);
+    double *Mq = P, *Mp = Mq + D * E, *Tq = Mp + D * E, *G = Tq + D * E;
+    cplx *Wm = (cplx *)P;                             // BQ' iA'
+    cplx *V = (cplx *)P, *augM = V + DD, *hat = augM + dp * 2 * dp, *rho = hat + 5 * dp;
     cplx *c = (cplx *)f;
-    cplx *aug = c;               c += E * 2 * E;    // [A'/s | I] -> [I | s iA']
+    cplx *aug = c;               c += wm_region_q(D, dp);   // [A'/s | I] -> [I | s iA']
+    cplx *Gt = aug, *Gti = aug + DD;                  // Gt, later CQQ
     cplx *BQ = c;                c += D * E;
-    cplx *Wm = c;                c += D * E;        // BQ' iA'
-    cplx *Gt = c;                c += DD;           // Gt, later CQQ
-    cplx *Gti = c;               c += DD;
-    cplx *V = c;                 c += DD;           // Gti iGi0
-    cplx *augM = c;              c += dp * 2 * dp;  // [M'/(2pi) | I]
     cplx *colbuf = c;            c += E > D ? E : D;
     cplx *cv = c;                c += 5 * D;        // u_dq, u_n1, w_dQ(c), w_n1(c), y
-    cplx *hat = c;               c += 5 * dp;       // U^T of the five vectors
-    cplx *rho = c;               c += 5 * dp;       // iM' of them
-    double *rowtmp = (double *)c;                    // per-row partial results of the scalar tail (3 x D)
-    double *cst = rowtmp + 3 * D;                    // optional LDS copies of the constants
+    double *cst = (double *)c;                       // optional LDS copies of the constants
 
     // constants: global pointers, or LDS copies when the host found room for them
     const double *cU = W.U, *cGt = W.Gt, *cG0 = W.G0, *ciGi0 = W.iGi0, *cS = W.S, *cCqq = W.Cqq;
@@ -374,10 +382,10 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
 }
 
 size_t wm_lds_bytes(int D, int dp) {
-    const size_t E = 2 * (size_t)dp, DD = (size_t)D * D;
-    size_t doubles = 3 * D * E + E * E + 8 * D + 1;
-    size_t cplxs = E * 2 * E + 2 * D * E + 3 * DD + (size_t)dp * 2 * dp + (E > (size_t)D ? E : D) + 5 * D + 10 * dp;
-    return doubles * 8 + cplxs * 16 + 3 * (size_t)D * 8 + 32;
+    const size_t E = 2 * (size_t)dp;
+    const size_t doubles = 8 * (size_t)D + 3 * (size_t)D + (D & 1) + wm_region_p(D, dp);
+    const size_t cplxs = wm_region_q(D, dp) + (size_t)D * E + (E > (size_t)D ? E : D) + 5 * (size_t)D;
+    return doubles * 8 + cplxs * 16 + 32;
 }
 
 size_t wm_const_bytes(int D, int dp) { return ((size_t)D * dp + 5 * (size_t)D * D + 5 * (size_t)D) * 8; }
