@@ -177,6 +177,7 @@ def main():
             "metric": "trajectory-steps/sec + wall-time to converged C(t), anharmonic-AS D=60",
             "value": n * world * K / wall, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
+            "wall_time_of_timed_loop_s": wall,       # with --steps 2000: the wall time to the full C(t) of BASELINE configs[1]
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "anharmonic-AS 60-mode, HK, fp64, dt=0.005 fs (BASELINE.json configs[1])",
