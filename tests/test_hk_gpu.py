@@ -218,3 +218,28 @@ def test_row_wave_variant_matches_golden(monkeypatch):
         prop = engine_propagator(g)
         cauto, kic = prop.run(engine_potential(g), float(g["dt"]), int(g["nt"]), float(g["E0"]))
         assert cases.rel_err(cauto, g["cauto"]) < TOL and cases.rel_err(kic, g["kic"]) < TOL
+
+
+def test_unsupported_sizes_fail_loudly():
+    """no silent fallback: what the kernels cannot hold is refused with the C-ABI's error text"""
+    from semiclassical_amd import propagators as PR
+    from semiclassical_amd._lib import EngineError, lib, check, sc_state, sc_hk_consts, sc_potential, SC_POT_MORSE
+    torch.set_default_dtype(torch.float64)
+    D = 70
+    G = torch.diag(torch.linspace(0.5, 1.5, D))
+    q0 = torch.zeros(D)
+    # WM keeps every matrix of a trajectory in LDS: D = 70 does not fit
+    wm = PR.WaltonManolopoulosPropagator(G, G, 10.0, 10.0, device="cuda")
+    with pytest.raises(EngineError, match="LDS"):
+        wm.initial_conditions(q0, q0, G, ntraj=8)
+    # the fused step entry point is limited to D <= 64
+    st = sc_state(n=1, dim=D)
+    with pytest.raises(EngineError, match="outside 1..64"):
+        check(lib.sc_hk_step(sc_potential(kind=SC_POT_MORSE, dim=D), st, sc_hk_consts(dim=D, dprime=D, diag=1), 0.1, 0,
+                             None, None))
+    with pytest.raises(EngineError, match="null argument"):
+        check(lib.sc_hk_step(None, None, None, 0.1, 0, None, None))
+    # beyond the dense path's D <= 96
+    with pytest.raises(EngineError, match="outside 1..96"):
+        check(lib.sc_dense_mono_step(sc_state(n=1, dim=100), sc_hk_consts(dim=100, dprime=100, diag=1), None, None, None,
+                                     0.0, 1, None))
