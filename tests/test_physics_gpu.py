@@ -59,3 +59,54 @@ def test_ic_correlation_matches_exact_quantum_result(kind, chi_tag):
     assert abs(cauto[0] - 1.0) < 1e-2
     scale = np.max(np.abs(qm))
     assert np.max(np.abs(kic - qm)) < 0.1 * scale, np.max(np.abs(kic - qm)) / scale
+
+
+def _split_operator_1d(nt, dt):
+    """exact quantum dynamics on a grid for the 1-D model of Herman & Kluk (1986): V = eps/(2 b^2)(1 - e^{-b x})^2 +
+    (1 - eps) x^2/2, eps = 0.975, b = 12^(-1/2), Gaussian at x0 = 7.3 of width alpha = 1/2 (the vibrational ground state
+    of the upper surface).  Second-order-in-substeps split operator (20 substeps per step), as the reference's
+    tests/test_propagators.py:143-246 sets it up.  Returns <phi0|phi(t)> and hbar^-2 e^{i t E0} <V+phi0|e^{-iHt}|V+phi0>
+    for the coupling operator V = (hbar^2/m) d/dx (unit coupling vector)."""
+    nx, m = 10000, 20
+    x = np.linspace(-10.0, 40.0, nx)
+    dx = x[1] - x[0]
+    eps, b = 0.975, 12.0 ** -0.5
+    v = eps / (2 * b ** 2) * (1.0 - np.exp(-b * x)) ** 2 + (1.0 - eps) * 0.5 * x ** 2
+    k = 2.0 * np.pi * np.fft.fftfreq(nx, d=dx)
+    expT, expV = np.exp(-1j * k ** 2 / 2.0 * (dt / m)), np.exp(-1j * v * (dt / m))
+    phi0 = (1.0 / np.pi) ** 0.25 * np.exp(-0.5 * (x - 7.3) ** 2)
+    out = []
+    for psi0 in (phi0.astype(complex), np.fft.ifft(1j * k * np.fft.fft(phi0))):
+        psi, corr = psi0.copy(), np.zeros(nt, dtype=complex)
+        for t in range(nt):
+            corr[t] = np.sum(psi0.conj() * psi) * dx
+            for _ in range(m):
+                psi = expV * np.fft.ifft(expT * np.fft.fft(psi))
+        out.append(corr)
+    times = dt * np.arange(nt)
+    return out[0], np.exp(0.5j * times) * out[1]
+
+
+@pytest.mark.parametrize("kind", ["HK", "WM"])
+def test_1d_model_matches_exact_quantum_dynamics(kind):
+    """reference tests/test_propagators.py:115-327 (TestSemiclassicalPropagators1D): autocorrelation and IC correlation
+    of the anharmonic 1-D model against split-operator quantum dynamics within 5 % (10 % for the IC correlation), and the
+    norm of the semiclassical wavefunction within 5 % of one, with 50 000 trajectories"""
+    from semiclassical_amd import potentials as P, propagators as PR
+    nt = 100
+    times = np.linspace(0.0, 12.0 / 40 * 2.0 * np.pi, nt)
+    dt = float(times[1] - times[0])
+    c_qm, k_qm = _split_operator_1d(nt, dt)
+    pot = P.NonHarmonicPotential()
+    Gi, G0 = torch.tensor([[5.0]]), torch.tensor([[1.0]])
+    if kind == "HK":
+        prop = PR.HermanKlukPropagator(Gi, Gi, device="cuda")
+    else:
+        prop = PR.WaltonManolopoulosPropagator(Gi, Gi, 100.0, 100.0, device="cuda")
+    prop.initial_conditions(torch.tensor([7.3]), torch.tensor([0.0]), G0, ntraj=50000,
+                            generator=torch.Generator().manual_seed(0))
+    c, k = prop.run(pot, dt, nt, 0.5)
+    c = c * np.exp(-0.5j * dt * np.arange(nt))      # the reference compares autocorrelation() WITHOUT the e^{itE0} phase
+    assert np.max(np.abs(c - c_qm)) < 0.05 * np.max(np.abs(c_qm))
+    assert np.max(np.abs(k - k_qm)) < 0.1 * np.max(np.abs(k_qm))
+    assert abs(prop.norm() - 1.0) < 0.05
