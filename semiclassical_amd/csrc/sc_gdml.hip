@@ -316,7 +316,8 @@ struct StageArgs {
     double *epart;
 };
 
-__global__ __launch_bounds__(256) void gdml_stage_kernel(StageArgs A) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
     extern __shared__ double smem[];
     const int D = A.st.dim, tid = threadIdx.x, nth = blockDim.x, s = A.stage;
     const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train);
@@ -395,8 +396,15 @@ extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const s
     if (st->n <= 0) return SC_OK;
     const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8;
     StageArgs a{*g, *st, *sc, dt, stage, energy_partials};
-    if (hipFuncSetAttribute((const void *)gdml_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return sc_check_launch("sc_gdml_stage (LDS attribute)");
-    hipLaunchKernelGGL(gdml_stage_kernel, dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a);
+    // big molecules: LDS allows one workgroup per CU anyway, so give a geometry eight wavefronts instead of four
+    if (g->n_atoms * (g->n_atoms + 1) / 2 > 256) {
+        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sc_check_launch("sc_gdml_stage (LDS attribute)");
+        hipLaunchKernelGGL(gdml_stage_kernel<512>, dim3(sc_dense_grid(st->n)), dim3(512), lds, (hipStream_t)stream, a);
+    } else {
+        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sc_check_launch("sc_gdml_stage (LDS attribute)");
+        hipLaunchKernelGGL(gdml_stage_kernel<256>, dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a);
+    }
     return sc_check_launch("sc_gdml_stage");
 }
