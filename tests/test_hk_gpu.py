@@ -243,3 +243,28 @@ def test_unsupported_sizes_fail_loudly():
     with pytest.raises(EngineError, match="outside 1..96"):
         check(lib.sc_dense_mono_step(sc_state(n=1, dim=100), sc_hk_consts(dim=100, dprime=100, diag=1), None, None, None,
                                      0.0, 1, None))
+
+
+@pytest.mark.parametrize("n", [1, 3, 65])
+def test_ragged_trajectory_counts(n):
+    """a single trajectory / counts that fill no tile or wavefront: HK (dense state and shortcut) and WM against the
+    oracle on the first n golden initial conditions"""
+    from tests.engine_cases import engine_potential
+    from semiclassical_amd import propagators as PR
+    from oracle import sc_oracle as orc
+    torch.set_default_dtype(torch.float64)            # the oracle follows the reference's global default (cli.py:121)
+    g = cases.load("hk_as5_chi002")
+    pot, opot = engine_potential(g), cases.oracle_potential(g)
+    Gi = cases.T(g["Gamma_i"])
+    zi, probi = cases.T(g["zi"])[:, :n].contiguous(), cases.T(g["probi"])[:n].contiguous()
+    for make_ref, make_eng in ((lambda: orc.HKOracle(Gi, Gi), lambda: PR.HermanKlukPropagator(Gi, Gi, device="cuda")),
+                               (lambda: orc.HKOracle(Gi, Gi),
+                                lambda: PR.HermanKlukPropagator(Gi, Gi, device="cuda", exploit_separability=True)),
+                               (lambda: orc.WMOracle(Gi, Gi, 100.0, 100.0),
+                                lambda: PR.WaltonManolopoulosPropagator(Gi, Gi, 100.0, 100.0, device="cuda"))):
+        ref, prop = make_ref(), make_eng()
+        ref.set_initial_conditions(cases.T(g["q0"]), cases.T(g["p0"]), cases.T(g["Gamma_0"]), zi, probi)
+        prop.set_initial_conditions(cases.T(g["q0"]), cases.T(g["p0"]), cases.T(g["Gamma_0"]), zi, probi)
+        rc, rk = orc.run_loop(ref, opot, float(g["dt"]), 6, float(g["E0"]))
+        c, k = prop.run(pot, float(g["dt"]), 6, float(g["E0"]))
+        assert cases.rel_err(c, rc) < 1e-8 and cases.rel_err(k, rk) < 1e-8
