@@ -37,10 +37,10 @@ struct GdmlLds {
     double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *XJ, *AJ, *xsL, *aL, *red;
 };
 
-#define GDML_CHUNK 16
+#define GDML_CHUNK_MAX 16     // training points staged per chunk (run-time choice: 16, 8 or 4, by the LDS budget)
 #define GDML_NB 2            // atom-pair blocks of the Hessian per thread and group
 
-__device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt) {
+__device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt, int chunk) {
     GdmlLds L;
     double *f = base;
     L.red = f;  f += 32;
@@ -53,21 +53,21 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt) {
     L.wm = f;   f += Mt;
     L.ea = f;   f += Mt;
     L.grad = f; f += 3 * N;
-    L.XJ = f;   f += GDML_CHUNK * 3 * N;
-    L.AJ = f;   f += GDML_CHUNK * 3 * N;
-    L.xsL = f;  f += GDML_CHUNK * Dd;       // training descriptors / coefficients of the chunk: staged once (coalesced),
-    L.aL = f;   f += GDML_CHUNK * Dd;       // then read 2 (N-1) times each by the J^T products
+    L.XJ = f;   f += chunk * 3 * N;
+    L.AJ = f;   f += chunk * 3 * N;
+    L.xsL = f;  f += chunk * Dd;       // training descriptors / coefficients of the chunk: staged once (coalesced),
+    L.aL = f;   f += chunk * Dd;       // then read 2 (N-1) times each by the J^T products
     return L;
 }
 
-size_t gdml_lds_doubles(int N, int Dd, int Mt) {
-    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + 2 * (size_t)GDML_CHUNK * 3 * N +
-           2 * (size_t)GDML_CHUNK * Dd;
+size_t gdml_lds_doubles(int N, int Dd, int Mt, int chunk) {
+    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + 2 * (size_t)chunk * 3 * N +
+           2 * (size_t)chunk * Dd;
 }
 
 // V (without origin), grad[3N] (LDS, L.grad) and hess[3N][3N] (global, row-major) at the geometry in L.pos.
 // Every thread returns the energy.
-__device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess) {
+__device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess, int chunk) {
     const int N = G.n_atoms, Dd = G.n_desc, Mt = G.n_train, X = 3 * N;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
     const double q = G.q;
@@ -115,7 +115,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     __syncthreads();
     // ---- gradient in descriptor space, then Cartesian gradient
     // every wavefront takes a slice of the training points (lanes over the descriptor: coalesced rows), the per-wave
-    // partial sums meet in LDS (L.xsL, GDML_CHUNK * Dd doubles, is free at this point and holds nw <= 16 rows)
+    // partial sums meet in LDS (L.xsL and L.aL are contiguous and free at this point: 2 * chunk >= nw rows of Dd)
     for (int d0 = 0; d0 < Dd; d0 += 64) {
         const int d = d0 + lane;
         double g = 0.0;
@@ -213,8 +213,8 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
 #pragma unroll
                 for (int v = 0; v < 3; ++v) h[sl][u][v] = 0.0;
         }
-        for (int m0 = 0; m0 < Mt; m0 += GDML_CHUNK) {
-            const int mc = min(GDML_CHUNK, Mt - m0);
+        for (int m0 = 0; m0 < Mt; m0 += chunk) {
+            const int mc = min(chunk, Mt - m0);
             __syncthreads();
             // the chunk's training rows m0 .. m0+mc-1 are contiguous: coalesced global -> LDS.  (Read straight from L2
             // by the J^T products they cost 8 scattered bytes per multiply-add: the launch was L2-bandwidth bound.)
@@ -287,6 +287,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
 // ------------------------------------------------------------------ function-level evaluation
 struct EvalArgs {
     sc_gdml_model G;
+    int chunk;
     const double *r;
     int64_t n;
     double *energy, *grad, *hess;
@@ -295,12 +296,12 @@ struct EvalArgs {
 __global__ __launch_bounds__(256) void gdml_eval_kernel(EvalArgs A) {
     extern __shared__ double smem[];
     const int X = 3 * A.G.n_atoms;
-    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train);
+    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train, A.chunk);
     for (int64_t tr = blockIdx.x; tr < A.n; tr += gridDim.x) {
         __syncthreads();
         for (int i = threadIdx.x; i < X; i += blockDim.x) L.pos[i] = A.r[tr * X + i];
         __syncthreads();
-        const double e = gdml_eval_device(A.G, L, A.hess + (size_t)tr * X * X);
+        const double e = gdml_eval_device(A.G, L, A.hess + (size_t)tr * X * X, A.chunk);
         for (int i = threadIdx.x; i < X; i += blockDim.x) A.grad[tr * X + i] = L.grad[i];
         if (threadIdx.x == 0) A.energy[tr] = e - A.G.origin;
     }
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256) void gdml_eval_kernel(EvalArgs A) {
 // ------------------------------------------------------------------ RK4 stage of (q, p, S)
 struct StageArgs {
     sc_gdml_model G;
+    int chunk;
     sc_state st;
     sc_dense_scratch sc;
     double dt;
@@ -320,7 +322,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
     extern __shared__ double smem[];
     const int D = A.st.dim, tid = threadIdx.x, nth = blockDim.x, s = A.stage;
-    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train);
+    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train, A.chunk);
     const double dt = A.dt, c = (s == 0) ? 0.0 : (s == 3 ? dt : 0.5 * dt), w = (s == 0 || s == 3) ? 1.0 : 2.0;
     const double h6 = dt / 6.0;
     double esum = 0.0;
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
             ps[j] = qp[D + i] + c * kp;
         }
         __syncthreads();
-        const double e = gdml_eval_device(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D) - A.G.origin;
+        const double e = gdml_eval_device(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D, A.chunk) - A.G.origin;
         double tk[1] = {0.0};
         for (int i = tid, j = 0; i < D; i += nth, ++j) {
             const double im = A.G.inv_mass[i], kq = ps[j] * im, kp = -L.grad[i];
@@ -355,12 +357,22 @@ __global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
     if (tid == 0 && A.epart && s == 3) A.epart[blockIdx.x] = esum;
 }
 
+// training points per staged chunk: the largest of 16, 8, 4 that fits LDS (measured at 30 atoms: a smaller chunk that
+// lets two workgroups share a CU is slower -- more chunk iterations, each with three barriers); the per-wave partial
+// sums of the descriptor gradient need 2 * chunk >= wavefronts
+int gdml_chunk(const sc_gdml_model *g, int threads) {
+    const int minc = threads / 64 / 2 > 4 ? threads / 64 / 2 : 4;
+    for (int c = GDML_CHUNK_MAX; c >= minc; c /= 2)
+        if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, c) * 8 <= 160 * 1024) return c;
+    return 0;
+}
+
 int check_model(const sc_gdml_model *g, const char *who) {
     if (!g || !g->xs_train || !g->jx_alphas || !g->pair_k || !g->pair_l)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null model field", who);
     if (g->n_desc != g->n_atoms * (g->n_atoms - 1) / 2)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: descriptor size %d does not match %d atoms", who, g->n_desc, g->n_atoms);
-    if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8 > 160 * 1024)
+    if (gdml_chunk(g, 512) == 0)
         return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d, M=%d) needs more than 160 KiB of LDS", who, g->n_atoms, g->n_train);
     return SC_OK;
 }
@@ -373,8 +385,9 @@ extern "C" int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, 
     if (rc) return rc;
     if (!r || !energy || !grad || !hess) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_eval: null argument");
     if (n <= 0) return SC_OK;
-    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8;
-    EvalArgs a{*g, r, n, energy, grad, hess};
+    const int chunk = gdml_chunk(g, 256);
+    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, chunk) * 8;
+    EvalArgs a{*g, chunk, r, n, energy, grad, hess};
     if (hipFuncSetAttribute((const void *)gdml_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sc_check_launch("sc_gdml_eval (LDS attribute)");
     const int grid = (int)(n < 1024 ? n : 1024);
@@ -394,10 +407,12 @@ extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const s
     if (stage < 0 || stage > 3) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_stage: stage %d", stage);
     if (st->dim > 512) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_stage: D=%d > 512", st->dim);
     if (st->n <= 0) return SC_OK;
-    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train) * 8;
-    StageArgs a{*g, *st, *sc, dt, stage, energy_partials};
+    const bool big = g->n_atoms * (g->n_atoms + 1) / 2 > 256;
+    const int chunk = gdml_chunk(g, big ? 512 : 256);
+    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, chunk) * 8;
+    StageArgs a{*g, chunk, *st, *sc, dt, stage, energy_partials};
     // big molecules: LDS allows one workgroup per CU anyway, so give a geometry eight wavefronts instead of four
-    if (g->n_atoms * (g->n_atoms + 1) / 2 > 256) {
+    if (big) {
         if (hipFuncSetAttribute((const void *)gdml_stage_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sc_check_launch("sc_gdml_stage (LDS attribute)");
         hipLaunchKernelGGL(gdml_stage_kernel<512>, dim3(sc_dense_grid(st->n)), dim3(512), lds, (hipStream_t)stream, a);
