@@ -381,6 +381,156 @@ __global__ __launch_bounds__(256) void hk_modes_kernel(StepArgs A) {
     if (threadIdx.x == 0 && A.epart) A.epart[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+
+// ---- D <= 16: one WAVEFRONT per trajectory, everything in registers, no barrier and no LDS hand-off in the elimination.
+// Lane (rg, tj) = (lane >> 4, lane & 15) holds column tj of the matrix rows rg, rg + 4, rg + 8, rg + 12 (rows and
+// columns beyond D are padded with the identity), for the four monodromy blocks and the prefactor matrix alike; a
+// load / store instruction covers four 128-byte row segments.  The modes (RK4 of q, p, S and the row propagators P_a)
+// are done by the first D lanes of the same wavefront; P_a reaches the lanes that hold row a through a per-wave LDS
+// array.  Elimination, fully unrolled over the pivot row k (so its DPP row rg_k = k & 3 and register k >> 2 are
+// static): the pivot column is the largest live entry of the WHOLE row (all columns sit in one 16-lane DPP row: true
+// partial pivoting, no fallback needed), the scaled pivot row crosses to the other DPP rows by ds_bpermute, the
+// multipliers come from lane (rg, pl) by the same 64-bit DPP row_newbcast / computed jump as in the big kernel, and the
+// sign of the column permutation is accumulated from the live-column mask.
+template <bool STEP>
+__global__ __launch_bounds__(256) void hk_step_w16_kernel(StepArgs A) {
+    __shared__ double prop[4][4][16];
+    __shared__ double wsum[4];
+    const int D = A.st.dim, DD = D * D, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = lane >> 4, tj = lane & 15;
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    const bool colok = tj < D;
+    const double sib = colok ? A.hk.si[tj] : 1.0, isib = 1.0 / sib;
+    double sta[4], ista[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int r = rg + 4 * s;
+        sta[s] = r < D ? A.hk.st[r] : 1.0;
+        ista[s] = 1.0 / sta[s];
+    }
+    double esum = 0.0;
+    for (int64_t tr = (int64_t)blockIdx.x * 4 + wave; tr < A.st.n; tr += (int64_t)gridDim.x * 4) {
+        double *qp = A.st.qp + tr * 2 * D;
+        double *M = A.st.mono + tr * 4 * (int64_t)DD;
+        double p11[4] = {1, 1, 1, 1}, p12[4] = {0, 0, 0, 0}, p21[4] = {0, 0, 0, 0}, p22[4] = {1, 1, 1, 1};
+        if (STEP) {
+            double red5[5] = {0, 0, 0, 0, 0};
+            if (lane < D) {
+                const double q = qp[lane], p = qp[D + lane], im = A.pot.inv_mass[lane];
+                const double c0 = A.pot.par0[lane], c1 = A.pot.par1 ? A.pot.par1[lane] : 0.0;
+                double v, g, h1, h2, h3, h4;
+                sep_eval(A.pot.kind, c0, c1, q, v, g, h1);
+                const double kq1 = p * im, kp1 = -g;
+                red5[0] = 0.5 * p * p * im - v;
+                const double q2 = q + hh * kq1, p2 = p + hh * kp1;
+                sep_eval(A.pot.kind, c0, c1, q2, v, g, h2);
+                const double kq2 = p2 * im, kp2 = -g;
+                red5[1] = 0.5 * p2 * p2 * im - v;
+                const double q3 = q + hh * kq2, p3 = p + hh * kp2;
+                sep_eval(A.pot.kind, c0, c1, q3, v, g, h3);
+                const double kq3 = p3 * im, kp3 = -g;
+                red5[2] = 0.5 * p3 * p3 * im - v;
+                const double q4 = q + dt * kq3, p4 = p + dt * kp3;
+                sep_eval(A.pot.kind, c0, c1, q4, v, g, h4);
+                const double kq4 = p4 * im, kp4 = -g;
+                red5[3] = 0.5 * p4 * p4 * im - v;
+                red5[4] = 0.5 * p4 * p4 * im + v;
+                qp[lane] = q + h6 * (kq1 + 2.0 * kq2 + 2.0 * kq3 + kq4);
+                qp[D + lane] = p + h6 * (kp1 + 2.0 * kp2 + 2.0 * kp3 + kp4);
+                double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0;
+                rk4_pair(u1, v1, im, h1, h2, h3, h4, dt);
+                rk4_pair(u2, v2, im, h1, h2, h3, h4, dt);
+                prop[wave][0][lane] = u1; prop[wave][1][lane] = u2; prop[wave][2][lane] = v1; prop[wave][3][lane] = v2;
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) red5[i] = wave_sum(red5[i]);
+            if (lane == 0) {
+                A.st.act[tr] += h6 * (red5[0] + 2.0 * red5[1] + 2.0 * red5[2] + red5[3]);
+                esum += red5[4];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int r = rg + 4 * s;
+                if (r < D) { p11[s] = prop[wave][0][r]; p12[s] = prop[wave][1][r]; p21[s] = prop[wave][2][r]; p22[s] = prop[wave][3][r]; }
+            }
+        }
+        // ---- phase B
+        cplx m[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int r = rg + 4 * s;
+            const bool ok = colok && r < D;
+            const int e = r * D + tj;
+            double mqq = ok ? M[e] : 0.0, mqp = ok ? M[DD + e] : 0.0, mpq = ok ? M[2 * DD + e] : 0.0, mpp = ok ? M[3 * DD + e] : 0.0;
+            if (STEP) {
+                const double nqq = fma(p12[s], mpq, p11[s] * mqq), npq = fma(p22[s], mpq, p21[s] * mqq);
+                const double nqp = fma(p12[s], mpp, p11[s] * mqp), npp = fma(p22[s], mpp, p21[s] * mqp);
+                mqq = nqq; mpq = npq; mqp = nqp; mpp = npp;
+                if (ok) { M[e] = mqq; M[DD + e] = mqp; M[2 * DD + e] = mpq; M[3 * DD + e] = mpp; }
+            }
+            m[s] = ok ? c_make(0.5 * (sta[s] * isib * mqq + ista[s] * sib * mpp),
+                               0.5 * (-SC_HBAR * sta[s] * sib * mqp + (1.0 / SC_HBAR) * ista[s] * isib * mpq))
+                      : c_make(r == tj ? 1.0 : 0.0, 0.0);
+        }
+        // ---- phase C
+        cplx det = c_make(1.0, 0.0);
+        bool live = colok, singular = false;
+        int parity = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < D && !singular) {
+                constexpr int dummy = 0; (void)dummy;
+                const int rgk = k & 3, sk = k >> 2;
+                const int blk = (__double2hiint(c_abs2(m[sk])) & ~15) | (15 - tj);
+                const int keymax = row16_max_i32((live && rg == rgk) ? blk : -1);
+                const int kb = __builtin_amdgcn_readlane(keymax, 16 * rgk);
+                const int pl = 15 - (kb & 15);
+                const int src = 16 * rgk + pl;
+                const cplx piv = c_make(readlane_f64(m[sk].x, src), readlane_f64(m[sk].y, src));
+                if (piv.x == 0.0 && piv.y == 0.0) { singular = true; }
+                else {
+                    det = c_mul(det, piv);
+                    const cplx inv = c_inv_fast(piv);
+                    // sign of the column permutation: live columns to the left of the pivot column
+                    const unsigned long long lm = __ballot(live && rg == 0);
+                    parity ^= __popcll(lm & ((1ull << pl) - 1ull)) & 1;
+                    // scaled pivot row at this lane's column (from DPP row rgk)
+                    const cplx rowv = c_make(__shfl(m[sk].x, 16 * rgk + tj, 64), __shfl(m[sk].y, 16 * rgk + tj, 64));
+                    const bool keep = live && tj != pl;
+                    const cplx rs = c_mul(rowv, inv);
+                    const cplx r = c_make(keep ? rs.x : 0.0, keep ? rs.y : 0.0);
+                    cplx c[4];
+                    column_fetch_n(pl, m[0], m[1], m[2], m[3], c[0], c[1], c[2], c[3]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if (rg + 4 * s <= k) c[s] = c_make(0.0, 0.0);        // rows 0..k are finished
+                        m[s] = c_fnma(c[s], r, m[s]);
+                    }
+                    live = live && tj != pl;
+                }
+            }
+        }
+        if (lane == 0) {
+            if (singular) det = c_make(0.0, 0.0);
+            else if (parity) det = c_make(-det.x, -det.y);
+            cplx *c2 = (cplx *)A.st.c2;
+            if (STEP) {
+                const cplx prev = c2[tr];
+                if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
+            } else {
+                A.st.sgn[tr] = 1.0;
+            }
+            c2[tr] = det;
+        }
+    }
+    if (lane == 0) wsum[wave] = esum;
+    __syncthreads();
+    if (threadIdx.x == 0 && A.epart && STEP) A.epart[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 }  // namespace
 
 // launch the fast path; the caller has validated the arguments (separable potential, diag prefactor, D <= 64)
@@ -388,6 +538,16 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     const int D = a.st.dim, nr = (D + 15) / 16, grid = sc_step_grid(a.st.n, D);
     const char *occ_env = getenv("SC_SD_OCC");      // experiment knob: waves per SIMD the NR=4 kernel is compiled for
     const int occ = occ_env ? atoi(occ_env) : 4;
+    if (D <= 16 && !getenv("SC_NO_WAVE_KERNEL")) {
+        // partial sums: only the first `wg` entries are written, the energy guard adds sc_step_grid() of them
+        const int64_t quads = (a.st.n + 3) / 4;
+        const int wg = (int)(quads < 2048 ? quads : 2048);
+        if (a.epart && hipMemsetAsync(a.epart, 0, sizeof(double) * (size_t)grid, s) != hipSuccess)
+            return sc_check_launch("sc_hk_step (partials)");
+        if ((a.mode & 0xff) == 0) hipLaunchKernelGGL(hk_step_w16_kernel<true>, dim3(wg), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(hk_step_w16_kernel<false>, dim3(wg), dim3(256), 0, s, a);
+        return sc_check_launch("sc_hk_step (one wavefront per trajectory)");
+    }
     if ((a.mode & 0xff) == 0) hipLaunchKernelGGL(hk_modes_kernel, dim3(grid), dim3(256), 0, s, a);
     const bool step = (a.mode & 0xff) == 0;
 #define SC_LAUNCH_SD(NR_, OCC_)                                                                                \
