@@ -268,3 +268,37 @@ def test_ragged_trajectory_counts(n):
         rc, rk = orc.run_loop(ref, opot, float(g["dt"]), 6, float(g["E0"]))
         c, k = prop.run(pot, float(g["dt"]), 6, float(g["E0"]))
         assert cases.rel_err(c, rc) < 1e-8 and cases.rel_err(k, rk) < 1e-8
+
+
+@pytest.mark.parametrize("D", [2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64])
+def test_fast_path_at_tile_boundaries(D):
+    """dimensions around the 16-row / 16-column tile edges of the fast kernels (one row in the last block, full blocks,
+    ...): anharmonic AS model of D modes, dense-state kernel AND diagonal shortcut against the CPU oracle, plus a dense
+    random monodromy pushed through the register elimination"""
+    import bench
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    omega, chi, nac, q0, _ = bench.as60_model(D)
+    dt, n, nt = 4.0, 12, 3
+    G = torch.diag(omega)
+    E0 = float(0.5 * omega.sum())
+    ref = orc.HKOracle(G, G)
+    torch.manual_seed(D)
+    ref.initial_conditions(q0, 0.0 * q0, G, ntraj=n)
+    rc, rk = orc.run_loop(ref, orc.MorseOracle(omega, chi.clone(), nac), dt, nt, E0)
+    for kw in ({}, {"exploit_separability": True}):
+        prop = PR.HermanKlukPropagator(G, G, device="cuda", **kw)
+        prop.set_initial_conditions(q0, 0.0 * q0, G, ref.zi, ref.probi)
+        c, k = prop.run(P.MorsePotential(omega, chi.clone(), nac), dt, nt, E0)
+        assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-9
+        assert cases.rel_err(cnp(prop.y), ref.y.numpy()) < 1e-10
+    # dense random blocks: prefactor of the engine vs the oracle's (pivoting, fallback)
+    y = ref.y.clone()
+    gen = torch.Generator().manual_seed(100 + D)
+    y[2 * D:2 * D + 4 * D * D] += 0.2 * torch.randn((4 * D * D, n), generator=gen)
+    ref.y = y
+    ref._prefactor()
+    prop.y = y.cuda()
+    prop._prefactor_initial()
+    assert cases.rel_err(cnp(prop._c2), ref.c2.numpy()) < 1e-9
