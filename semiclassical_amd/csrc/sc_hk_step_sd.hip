@@ -250,10 +250,14 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         }
 
         // ---------------- phase B ----------------
+        // LDS indices derived from til / tjl are recomputed per trajectory: hipcc otherwise hoists them out of the
+        // trajectory loop, spills them, and reloads them one by one behind s_waitcnt vmcnt(0) in the middle of the stream
+        int til = ti, tjl = tj;
+        __asm__ volatile("" : "+v"(til), "+v"(tjl));
         cplx m[NR][NR];
 #pragma unroll
         for (int ra = 0; ra < NR; ++ra) {
-            const int a = 16 * ra + ti;
+            const int a = 16 * ra + til;
             const bool rowok = a < D;
             const int al = a & 63;
             const double p11 = prop[al], p12 = prop[64 + al], p21 = prop[128 + al], p22 = prop[192 + al];
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                     mqq = nqq; mpq = npq; mqp = nqp; mpp = npp;
                     if (ok) { pe[toff] = mqq; pe[DD + toff] = mqp; pe[2 * DD + toff] = mpq; pe[3 * DD + toff] = mpp; }
                 }
-                const int bl = b & 63;
+                const int bl = (16 * rb + tjl) & 63;
                 const double sib = scl[128 + bl], isib = scl[192 + bl];
                 m[ra][rb] = ok ? c_make(0.5 * (sta * isib * mqq + ista * sib * mpp),
                                         0.5 * (-SC_HBAR * sta * sib * mqp + (1.0 / SC_HBAR) * ista * isib * mpq))
