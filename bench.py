@@ -108,14 +108,45 @@ def separable_shortcut(pot, omega, q0, dt, E0, n, K, W, dev):
                     "diagonal prefactor; NOT the dense-state kernel the roofline object describes"}
 
 
-def main():
+def launch_check():
+    """--launch-check: every rank joins a gloo group, proves it with one all-reduce and reports its coordinates.
+    Exercises the self-launcher without a GPU and without importing the engine (tests/test_distributed.py)."""
+    import torch.distributed as dist
+    from semiclassical_amd import distributed as D
+    rank, world, local = D.init_from_env(backend="gloo")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    assert "semiclassical_amd._lib" not in sys.modules
+    print(json.dumps({"rank": rank, "world": world, "local_rank": local, "sum": float(t.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ntraj", type=int, default=100000, help="trajectories per GPU")
+    ap.add_argument("--ntraj", type=int, default=None, help="trajectories per GPU (default 100000 = BASELINE configs[1])")
+    ap.add_argument("--ntraj-total", type=int, default=None,
+                    help="trajectories of the whole job, sharded over the GPUs (default at --gpus 8: 10^6 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration lines (configs object)")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Self-launch: this parent never touches the GPU; it starts one fresh interpreter per GPU (rank r -> cuda:r,
+        # RCCL process group over 127.0.0.1) and exits with their status.  Rank 0 prints the JSON line.
+        from semiclassical_amd import distributed as D
+        sys.exit(D.launch_local_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if args.launch_check:
+        return launch_check()
 
     torch.set_default_dtype(torch.float64)
     from semiclassical_amd import distributed as D
@@ -126,15 +157,21 @@ def main():
     import torch.distributed as dist
     from semiclassical_amd import potentials as P, propagators as PR
 
+    if args.ntraj_total is None and args.ntraj is None and world == 8:
+        args.ntraj_total = 1000000            # BASELINE.json configs[3]: 10^6 trajectories over 8 GPUs
+    if args.ntraj_total is not None:
+        n, n_total = D.shard_count(args.ntraj_total, rank, world), args.ntraj_total
+    else:
+        n = 100000 if args.ntraj is None else args.ntraj
+        n_total = n * world
     omega, chi, nac, q0, dt = as60_model()
     dim = omega.shape[0]
     G = torch.diag(omega)
     E0 = float(0.5 * omega.sum())
-    n = args.ntraj
     pot = P.MorsePotential(omega, chi.clone(), nac)
     prop = PR.HermanKlukPropagator(G, G, device=dev)
     gen = torch.Generator().manual_seed(1234 + rank)
-    prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, ntraj_total=n * world, generator=gen)
+    prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, ntraj_total=n_total, generator=gen)
 
     K, W = args.steps, args.warmup
     slots = torch.zeros((K, 5), dtype=torch.float64, device=dev)
@@ -175,14 +212,14 @@ def main():
         traffic, traffic_source = profiled_traffic(n, dim)
         out = {
             "metric": "trajectory-steps/sec + wall-time to converged C(t), anharmonic-AS D=60",
-            "value": n * world * K / wall, "unit": "trajectory-steps/s",
+            "value": n_total * K / wall, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
             "wall_time_of_timed_loop_s": wall,       # with --steps 2000: the wall time to the full C(t) of BASELINE configs[1]
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "anharmonic-AS 60-mode, HK, fp64, dt=0.005 fs (BASELINE.json configs[1])",
-                       "trajectories_per_gpu": n, "trajectories_total": n * world, "dim": dim,
-                       "sharding": f"{world} x {n} trajectories, one all-reduce of 4*K doubles per flush"},
+                       "trajectories_per_gpu": n, "trajectories_total": n_total, "dim": dim,
+                       "sharding": f"{world} x {n} trajectories, one RCCL all-reduce of 4*K doubles per flush"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "hk_step_sd_kernel<4,4,true> (+ its hk_modes_kernel pre-pass, same event bracket)",

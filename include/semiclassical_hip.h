@@ -35,6 +35,10 @@
 extern "C" {
 #endif
 
+/* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
+ * library whose sc_abi_version() or struct sizes differ from its own declarations. */
+#define SC_ABI_VERSION        2
+
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
 #define SC_ERR_UNSUPPORTED   -2   /* shape outside what the kernels hold on chip */
@@ -152,6 +156,12 @@ typedef struct sc_dense_scratch {
 
 int         sc_version(void);
 const char *sc_last_error(void);
+/* ABI guard: SC_ABI_VERSION the library was compiled with; sizeof of the struct called `name` ("sc_state", ...), or
+ * -1 for an unknown name; 1 if the library is a tuning build (-DSC_TUNING: reads experiment knobs from the
+ * environment), 0 for the product build. */
+int sc_abi_version(void);
+int sc_struct_size(const char *name);
+int sc_tuning_build(void);
 
 /* number of workgroups sc_hk_step / sc_hk_correlate use for n trajectories of dimension D;
  * the caller sizes the `partials` buffers with it. */

@@ -69,8 +69,15 @@ SC_POT_MORSE, SC_POT_HARMONIC_SEP, SC_POT_EPS_MORSE, SC_POT_HARMONIC_DENSE = 1, 
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
+ABI_VERSION = 2              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
+           sc_dense_scratch)
+
 SIGNATURES = {
     "sc_version": (C.c_int, []),
+    "sc_abi_version": (C.c_int, []),
+    "sc_struct_size": (C.c_int, [C.c_char_p]),
+    "sc_tuning_build": (C.c_int, []),
     "sc_last_error": (C.c_char_p, []),
     "sc_step_grid": (C.c_int, [C.c_int64, C.c_int32]),
     "sc_correlate_grid": (C.c_int, [C.c_int64, C.c_int32]),
@@ -126,6 +133,14 @@ def _load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    # ABI guard: a stale or foreign build must fail here, not run with shifted struct fields
+    if lib.sc_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.sc_abi_version()}, these bindings need {ABI_VERSION}: "
+                          "rebuild with `python -m semiclassical_amd.build --force`")
+    for st in STRUCTS:
+        have = lib.sc_struct_size(st.__name__.encode())
+        if have != C.sizeof(st):
+            raise ImportError(f"{LIB_PATH}: sizeof({st.__name__}) is {have} in the library, {C.sizeof(st)} in the bindings")
     return lib
 
 

@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
 }  // namespace
 
 int sc_launch_step_sd(const StepArgs &a, hipStream_t s);   // sc_hk_step_sd.hip
-int sc_launch_step_rw(const StepArgs &a, hipStream_t s);   // sc_hk_step_rw.hip
+#ifdef SC_TUNING
+int sc_launch_step_rw(const StepArgs &a, hipStream_t s);   // tools/variants/sc_hk_step_rw.hip
+#endif
 
 static int step_threads(int D) { return D * D <= 256 ? 64 : 256; }
 
@@ -249,14 +251,19 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     const bool dense = pot->kind == SC_POT_HARMONIC_DENSE;
     if (!dense && pot->kind != SC_POT_MORSE && pot->kind != SC_POT_HARMONIC_SEP && pot->kind != SC_POT_EPS_MORSE)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown potential kind %d", pot->kind);
-    const bool fast = !dense && hk->diag && st->work && !getenv("SC_FORCE_GENERAL_STEP");
+    bool fast = !dense && hk->diag && st->work;
+    int dbg = 0;
+#ifdef SC_TUNING   // experiment knobs exist only in the tuning build (tools/mkvar.sh); the product library reads no environment
+    if (getenv("SC_FORCE_GENERAL_STEP")) fast = false;
+    dbg = (getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0) | (getenv("SC_DEBUG_FORCE_FIXUP") ? 0x400 : 0);
+#endif
     if (fast) {
-        const int dbg = (getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0) | (getenv("SC_DEBUG_FORCE_FIXUP") ? 0x400 : 0);
         StepArgs a{*pot, *st, *hk, dt, mode | dbg, energy_partials};
-        // SC_FAST_KERNEL=rw selects the row-wave layout (lane = column, full column pivoting, no fallback pass);
-        // measured slower on MI355X (12.2 ms vs 9.5 ms per step at D=60, n=1e5), kept as the reference variant
+#ifdef SC_TUNING
+        // SC_FAST_KERNEL=rw: the rejected row-wave layout of tools/variants/sc_hk_step_rw.hip
         const char *which = getenv("SC_FAST_KERNEL");
         if (which && which[0] == 'r') return sc_launch_step_rw(a, (hipStream_t)stream);
+#endif
         if (st->flags && hipMemsetAsync(st->flags + st->n, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
             return sc_check_launch("sc_hk_step (flag counter)");
         const int rc = sc_launch_step_sd(a, (hipStream_t)stream);

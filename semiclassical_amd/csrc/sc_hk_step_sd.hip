@@ -239,7 +239,11 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     int seq0 = 0;                                  // tags of this workgroup's pivot records: unique per (trajectory, block)
     for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += 4) {
         double *M = A.st.mono + tr * 4 * (int64_t)DD;
-        if (tid == 0) weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: debug, force the fallback (SC_DEBUG_FORCE_FIXUP)
+#ifdef SC_TUNING
+        if (tid == 0) weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: tuning build, force the fallback (SC_DEBUG_FORCE_FIXUP)
+#else
+        if (tid == 0) weak = 0;
+#endif
 
         if (do_step) {
             // row propagators P_a of this trajectory, computed by hk_modes_kernel ("phase A")
@@ -296,14 +300,19 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         // ---------------- phase C: determinant in registers ----------------
         cplx det = c_make(1.0, 0.0);
         bool singular = false;
-        if (!(A.mode & 0x100)) {                 // 0x100: debug, skip the elimination (SC_DEBUG_SKIP_LU)
+#ifdef SC_TUNING
+        const bool skip_lu = (A.mode & 0x100) != 0;      // tuning build only: phase ablation (SC_DEBUG_SKIP_LU)
+#else
+        constexpr bool skip_lu = false;
+#endif
+        if (!skip_lu) {
             eliminate_block<NR, 0>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, &weak);
             if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, &weak);
             if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, &weak);
             if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, &weak);
         }
         __syncthreads();
-        if (tid == 0 && weak && A.st.flags && !(A.mode & 0x100)) {
+        if (tid == 0 && weak && A.st.flags && !skip_lu) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
             atomicAdd(&A.st.flags[A.st.n], 1);   // lets the fix-up launch return at once when nothing was flagged
         } else if (tid == 0) {
@@ -540,9 +549,13 @@ __global__ __launch_bounds__(256) void hk_step_w16_kernel(StepArgs A) {
 // launch the fast path; the caller has validated the arguments (separable potential, diag prefactor, D <= 64)
 int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     const int D = a.st.dim, nr = (D + 15) / 16, grid = sc_step_grid(a.st.n, D);
-    const char *occ_env = getenv("SC_SD_OCC");      // experiment knob: waves per SIMD the NR=4 kernel is compiled for
-    const int occ = occ_env ? atoi(occ_env) : 4;
-    if (D <= 16 && !getenv("SC_NO_WAVE_KERNEL")) {
+    int occ = 4;
+    bool wave_kernel = D <= 16;
+#ifdef SC_TUNING
+    if (const char *occ_env = getenv("SC_SD_OCC")) occ = atoi(occ_env);   // waves per SIMD the NR=4 kernel is compiled for
+    if (getenv("SC_NO_WAVE_KERNEL")) wave_kernel = false;
+#endif
+    if (wave_kernel) {
         // partial sums: only the first `wg` entries are written, the energy guard adds sc_step_grid() of them
         const int64_t quads = (a.st.n + 3) / 4;
         const int wg = (int)(quads < 2048 ? quads : 2048);
@@ -564,9 +577,12 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
         case 2: SC_LAUNCH_SD(2, 4); break;
         case 3: SC_LAUNCH_SD(3, 4); break;
         default:
-            if (occ >= 4) SC_LAUNCH_SD(4, 4);
-            else if (occ == 3) SC_LAUNCH_SD(4, 3);
-            else SC_LAUNCH_SD(4, 2);
+#ifdef SC_TUNING
+            if (occ == 3) { SC_LAUNCH_SD(4, 3); break; }
+            if (occ < 3) { SC_LAUNCH_SD(4, 2); break; }
+#endif
+            (void)occ;
+            SC_LAUNCH_SD(4, 4);
             break;
     }
 #undef SC_LAUNCH_SD

@@ -5,16 +5,26 @@ Trajectories are independent; the only coupling is the sum over trajectories in 
 accumulates the raw sums of each time step in a device buffer ``slots`` (nt, 5).  Because each term
 already carries the weight 1/(N_total P(qi,pi)), the global correlation functions are the plain SUM of
 the per-rank buffers: one all-reduce of 4*nt doubles per flush (RCCL over xGMI when the process group
-uses the ``nccl`` backend; ``gloo`` on CPU tensors for tests).  No other collective exists on the path.
+uses the ``nccl`` backend; ``gloo`` for tests, CUDA tensors are then staged through the host).  No other
+collective exists on the path.
+
+Process model: one process per GPU.  ``launch_local_ranks`` starts the rank processes of one node from a
+parent that never touches the GPU (it only counts to N and waits); ``init_from_env`` is what every rank
+calls first.  This module does not import the HIP engine.
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank)"""
+    """initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun or launch_local_ranks);
+    returns (rank, world, local_rank)"""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -22,11 +32,69 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_environment(rank, world, port, base=None):
+    """environment of rank `rank` of a single-node job: what torchrun would export"""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    return env
+
+
+def launch_local_ranks(argv, nproc, timeout=None, extra_env=None):
+    """Start ``nproc`` copies of ``python argv...`` as ranks 0..nproc-1 of one node and wait for them.
+
+    The caller must not have initialised the GPU: the children are fresh interpreters (plain fork+exec of
+    ``sys.executable``), rank r binds to cuda:r itself.  stdout / stderr are inherited, so rank 0's single
+    JSON line is the job's output.  Returns the largest exit code; on a failing or hung rank the others are
+    terminated (by PID).
+    """
+    port = free_port()
+    procs = []
+    for r in range(nproc):
+        env = rank_environment(r, nproc, port)
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
+    rc = 0
+    deadline = None if timeout is None else time.monotonic() + timeout
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = max(rc, code if code > 0 else 1)
+                    for o in pending:            # one rank died: the collective of the others would hang
+                        o.terminate()
+            if pending and deadline is not None and time.monotonic() > deadline:
+                rc = max(rc, 124)
+                for o in pending:
+                    o.terminate()
+                deadline = None
+            if pending:
+                time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def shard_count(n_total, rank, world):
@@ -35,14 +103,27 @@ def shard_count(n_total, rank, world):
     return base + (1 if rank < rem else 0)
 
 
+def shard_slice(n_total, rank, world):
+    """the contiguous index range of `rank`'s shard"""
+    lo = sum(shard_count(n_total, r, world) for r in range(rank))
+    return slice(lo, lo + shard_count(n_total, rank, world))
+
+
 def flush_correlations(slots, group=None):
     """sum the raw per-step correlation sums over all ranks, in place (columns 0..3 of ``slots``).
 
-    Column 4 (reserved) is left rank-local.  A single collective per call.
+    Column 4 (reserved) is left rank-local.  A single collective per call.  With the ``gloo`` backend a
+    device tensor is staged through the host (gloo reduces host memory); with ``nccl`` (RCCL) the
+    reduction runs on the device buffers directly.
     """
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return slots
     buf = slots[:, :4].contiguous()
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     slots[:, :4] = buf
     return slots

@@ -26,19 +26,27 @@ logger = logging.getLogger(__name__)
 
 
 class _DescriptorMixin(object):
-    """caches the device copies of the parameter vectors per device"""
+    """caches the device copies of the parameter vectors per device; a cached block is reused only while the host
+    parameters it was built from are unchanged (omega, chi, masses ... edited in place rebuild it)"""
 
     def _descriptor(self, device):
         cache = self.__dict__.setdefault("_desc_cache", {})
         key = str(device)
-        if key not in cache:
-            kind, par0, par1, par2, scalar0 = self._parameters()
-            up = lambda x: None if x is None else torch.as_tensor(x, dtype=torch.float64).contiguous().to(device)
-            bufs = [up(par0), up(par1), up(par2), up(1.0 / torch.as_tensor(self.masses(), dtype=torch.float64))]
-            desc = sc_potential(kind=kind, dim=self.dimensions(), par0=ptr(bufs[0]), par1=ptr(bufs[1]),
-                                par2=ptr(bufs[2]), scalar0=float(scalar0), inv_mass=ptr(bufs[3]))
-            cache[key] = (desc, bufs)           # bufs keeps the device memory alive
-        return cache[key][0]
+        kind, par0, par1, par2, scalar0 = self._parameters()
+        host = [None if x is None else torch.as_tensor(x, dtype=torch.float64).detach().cpu()
+                for x in (par0, par1, par2, self.masses())]
+        stamp = (kind, float(scalar0))
+        hit = cache.get(key)
+        if hit is not None and hit[2] == stamp and all(
+                (a is None and b is None) or (a is not None and b is not None and a.shape == b.shape and torch.equal(a, b))
+                for a, b in zip(hit[3], host)):
+            return hit[0]
+        up = lambda x: None if x is None else x.contiguous().to(device)
+        bufs = [up(host[0]), up(host[1]), up(host[2]), up(1.0 / host[3])]
+        desc = sc_potential(kind=kind, dim=self.dimensions(), par0=ptr(bufs[0]), par1=ptr(bufs[1]),
+                            par2=ptr(bufs[2]), scalar0=float(scalar0), inv_mass=ptr(bufs[3]))
+        cache[key] = (desc, bufs, stamp, [None if h is None else h.clone() for h in host])   # bufs keeps the memory alive
+        return desc
 
     def _invalidate_descriptor(self):
         self.__dict__.pop("_desc_cache", None)

@@ -35,6 +35,25 @@ C128 = torch.complex128
 F64 = torch.float64
 
 
+def _potential_fingerprint(potential):
+    """Identity of the constants a potential contributes to the cached device buffers (1/m, coupling vectors).
+
+    Caches are keyed on the object itself (a strong reference, compared with ``is``: a recycled ``id`` cannot alias a
+    dead potential) AND on this cheap content fingerprint, so that masses or coupling vectors changed in place are
+    picked up at the next step / run entry.  O(D) host work per call.
+    """
+    d = potential.dimensions()
+    probe = torch.zeros((d, 1), dtype=F64)
+    masses = hostmath.as_f64(potential.masses())
+    tau1 = hostmath.as_f64(potential.derivative_coupling_1st(probe))[:, 0]
+    tau2 = hostmath.as_f64(potential.derivative_coupling_2nd(probe))[:, 0]
+    return masses, tau1, tau2
+
+
+def _same_fingerprint(a, b):
+    return a is not None and b is not None and all(x.shape == y.shape and torch.equal(x, y) for x, y in zip(a, b))
+
+
 def _resolve_device(device):
     dev = torch.device(device)
     if dev.type != 'cuda':
@@ -63,8 +82,7 @@ class HermanKlukPropagator(object):
         self.Gamma_i, self.Gamma_t = Gamma_i.to(self.device), Gamma_t.to(self.device)
         self.sqGi, self.isqGi = hostmath.sym_sqrtm(Gamma_i)
         self.sqGt, self.isqGt = hostmath.sym_sqrtm(Gamma_t)
-        self._energy_means = None
-        self._nac = None
+        self._nac, self._nac_pot, self._nac_fp = None, None, None
         self._ntraj_norm = None
 
     # ------------------------------------------------------------------ initial conditions
@@ -132,7 +150,7 @@ class HermanKlukPropagator(object):
         self._elog = torch.zeros(4, dtype=F64, device=dev)            # energy guard log (sc_energy_guard)
         self._nsteps = 0
         self._corr_step, self._corr_has_nac = -1, False
-        self._nac, self._nac_key = None, None
+        self._nac, self._nac_pot, self._nac_fp = None, None, None
         self._dense = None
         # diagonals of the monodromy blocks for the separable shortcut; _mono is stale while they are ahead of it
         self._mdiag = torch.zeros((n, 4, d), dtype=F64, device=dev)
@@ -193,7 +211,9 @@ class HermanKlukPropagator(object):
         self._launch_step(potential, float(dt))
         self.t += float(dt)
 
-    def _launch_step(self, potential, dt):
+    def _launch_step(self, potential, dt, desc=None, remembered=False):
+        """``desc`` / ``remembered``: run() resolves the potential's device descriptor and coupling constants once per
+        call instead of once per step"""
         s = self._stream()
         timed = getattr(self, "profile_step_kernel", False)
         if timed:
@@ -208,7 +228,8 @@ class HermanKlukPropagator(object):
             self._sync_dense_mono(leave_diagonal=True)
             nblocks = self._launch_generic_step(potential, dt, s)
         else:
-            desc = self._potential_descriptor(potential)
+            if desc is None:
+                desc = self._potential_descriptor(potential)
             if self._shortcut_applies(desc):
                 check(lib.sc_hk_step_diag(desc, self._state, self._hk, ptr(self._mdiag), dt, 0, ptr(self._epart), s))
                 self._mono_stale = True
@@ -221,7 +242,8 @@ class HermanKlukPropagator(object):
             self.__dict__.setdefault("_step_events", []).append((e0, e1))
         check(lib.sc_energy_guard(ptr(self._epart), nblocks, float(self.ntraj), ptr(self._elog), s))
         self._nsteps += 1
-        self._remember_nac(potential)
+        if not remembered:
+            self._remember_nac(potential)
         self._after_prefactor(track=1)
 
     def _shortcut_applies(self, desc):
@@ -277,11 +299,12 @@ class HermanKlukPropagator(object):
         (generic Python potentials take the unfused path)."""
         n, d = self.ntraj, self.dim
         dense = self._dense_scratch()
-        key = id(potential)
-        if getattr(self, "_generic_key", None) != key:
-            self._generic_inv_mass = (1.0 / hostmath.as_f64(potential.masses())).to(self.device).contiguous()
+        masses = hostmath.as_f64(potential.masses())
+        cached = getattr(self, "_generic_masses", None)
+        if getattr(self, "_generic_pot", None) is not potential or cached is None or not torch.equal(cached, masses):
+            self._generic_inv_mass = (1.0 / masses).to(self.device).contiguous()
             self._generic_r = torch.empty((n, d), dtype=F64, device=self.device)
-            self._generic_key = key
+            self._generic_pot, self._generic_masses = potential, masses.clone()
         r, inv_mass = self._generic_r, self._generic_inv_mass
         for stage in range(4):
             check(lib.sc_stage_point(self._state, dense, dt, stage, ptr(r), s))
@@ -303,9 +326,8 @@ class HermanKlukPropagator(object):
 
     def _potential_descriptor(self, potential):
         if not hasattr(potential, "_descriptor"):
-            raise NotImplementedError(
-                f"{type(potential).__name__} has no device descriptor; use the potentials of "
-                "semiclassical_amd.potentials (generic Python potentials are not supported by the HIP engine yet).")
+            raise TypeError(f"{type(potential).__name__} has no device descriptor: it takes the unfused path "
+                            "(_launch_generic_step), not a fused kernel")
         with torch.cuda.device(self.device):
             return potential._descriptor(self.device)
 
@@ -319,27 +341,34 @@ class HermanKlukPropagator(object):
         torch.cuda.current_stream(self.device).synchronize()
         self._check_energy_guard()
 
+    def mean_energy(self):
+        """<T+V> over the trajectories as the energy guard saw it at the last step: the value at the k4 stage point
+        (reference propagators.py:380 ``_en_mean``, quirk Q2), not that of the accepted state.  Host sync."""
+        return float(self._elog[1].item())
+
     def step_kernel_times_ms(self):
         """durations of the step-kernel launches recorded while ``profile_step_kernel`` was set"""
         torch.cuda.current_stream(self.device).synchronize()
         return [e0.elapsed_time(e1) for e0, e1 in self.__dict__.get("_step_events", [])]
 
     # ------------------------------------------------------------------ correlation functions
+    def _nac_is_current(self, potential):
+        """(is the cached coupling data that of `potential`?, fingerprint of `potential`)"""
+        fp = _potential_fingerprint(potential)
+        return (self._nac_pot is potential and _same_fingerprint(self._nac_fp, fp)), fp
+
     def _remember_nac(self, potential):
-        key = id(potential)
-        if self._nac_key == key:
+        current, fp = self._nac_is_current(potential)
+        if current:
             return
-        masses = hostmath.as_f64(potential.masses())
-        probe = torch.zeros((self.dim, 1), dtype=F64)
-        tau1 = hostmath.as_f64(potential.derivative_coupling_1st(probe))[:, 0]
-        tau2 = hostmath.as_f64(potential.derivative_coupling_2nd(probe))[:, 0]
+        masses, tau1, tau2 = fp
         nc = hostmath.NacConstants(self._G0h, self._Gi, self._iGi0h, self._p0h, masses, tau1,
                                    tau2_sum=float(torch.sum(tau2 / masses)))
         dev = self.device
         bufs = [nc.rn.to(dev), nc.gn.to(dev)]
         self._nac = sc_nac_consts(dim=self.dim, rn=ptr(bufs[0]), gn=ptr(bufs[1]), q0=ptr(self.q0), p0=ptr(self.p0),
                                   p0n1=nc.p0n1, n2=nc.n2)
-        self._nac_bufs, self._nac_key = bufs, key
+        self._nac_bufs, self._nac_pot, self._nac_fp = bufs, potential, tuple(x.clone() for x in fp)
         self._nacq = torch.zeros(self.ntraj, dtype=C128, device=dev)
         check(lib.sc_nac_initial(self._nac, ptr(self._zi_t), self.ntraj, ptr(self._nacq), self._stream()))
 
@@ -395,17 +424,29 @@ class HermanKlukPropagator(object):
         own = slots is None
         if own:
             slots = torch.zeros((nt, 5), dtype=F64, device=self.device)
+        else:
+            self._check_slots(slots, nt)
         t0 = self.t
         base = slots.data_ptr()
+        fused = hasattr(potential, "_descriptor") and not hasattr(potential, "_gdml_model") and self.dim <= 64
+        desc = self._potential_descriptor(potential) if fused else None
         for k in range(nt):
             self._launch_correlate(base + 40 * k, per_trajectory=False)
-            self._launch_step(potential, dt)
+            self._launch_step(potential, dt, desc=desc, remembered=True)
             self.t += dt
         self._corr_step = -1
         if not own:
             return None
         self.synchronize()
         return self.finalize_slots(slots, t0, dt, energy0_es)
+
+    def _check_slots(self, slots, nt):
+        """the kernels write 5 doubles at slots + 40 k for k < nt: refuse anything that is not exactly that buffer"""
+        if not (isinstance(slots, torch.Tensor) and slots.dtype == F64 and slots.dim() == 2 and slots.shape[1] == 5
+                and slots.shape[0] >= nt and slots.is_contiguous() and slots.device == self.device):
+            raise ValueError(f"slots has to be a contiguous float64 tensor of shape (>= {nt}, 5) on {self.device}, got "
+                             f"{getattr(slots, 'dtype', type(slots))} {tuple(getattr(slots, 'shape', ()))} on "
+                             f"{getattr(slots, 'device', '?')}")
 
     @staticmethod
     def finalize_slots(slots, t0, dt, energy0_es):
@@ -531,6 +572,15 @@ class HermanKlukPropagator(object):
             raise KeyError(key)
         return self._sgn.type(C128)
 
+    _TRACKED = {"prefactorC": ("_sgn", "_c2")}
+
+    @property
+    def sign_trackers(self):
+        """the reference's bookkeeping dict (propagators.py:1006-1066): name -> {'signs': +-1 per trajectory,
+        'previous': value at the last tracked step}, built from the device-resident tracker state (read-only views)"""
+        return {name: {"signs": getattr(self, s).type(C128), "previous": getattr(self, z)}
+                for name, (s, z) in self._TRACKED.items()}
+
 
 def C_void(address):
     import ctypes
@@ -587,14 +637,11 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
             pre_coef=wm.pre_coef)
 
     def _remember_nac(self, potential):
-        key = id(potential)
-        if self._nac_key == key:
+        current, fp = self._nac_is_current(potential)
+        if current:
             return
         super()._remember_nac(potential)
-        masses = hostmath.as_f64(potential.masses())
-        probe = torch.zeros((self.dim, 1), dtype=F64)
-        tau1 = hostmath.as_f64(potential.derivative_coupling_1st(probe))[:, 0]
-        tau2 = hostmath.as_f64(potential.derivative_coupling_2nd(probe))[:, 0]
+        masses, tau1, tau2 = fp
         n1 = -hbar ** 2 * tau1 / masses
         wm = self._wm_host
         dev = self.device
@@ -676,6 +723,8 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         self._corr_step, self._corr_has_nac = self._nsteps, self._wm_has_nac
         self._slot_host = self._slot.cpu().numpy().copy()
         self._check_energy_guard()
+
+    _TRACKED = {"prefactorC": ("_sgn", "_c2"), "detA": ("_sgnA", "_detA"), "detM": ("_sgnM", "_detM")}
 
     def _get_signs_of_sqrt(self, key):
         if key == "detA":

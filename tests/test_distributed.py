@@ -1,12 +1,18 @@
 """The N > 1 path on CPU: two gloo ranks each own a shard; one all-reduce of the per-step sums per flush."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
 from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 torch.set_default_dtype(torch.float64)
 
@@ -82,3 +88,50 @@ def test_flush_is_identity_without_process_group():
     from semiclassical_amd import distributed as D
     s = torch.arange(10.0).reshape(2, 5)
     assert torch.equal(D.flush_correlations(s.clone()), s)
+
+
+def test_shard_slices_partition_the_batch():
+    from semiclassical_amd import distributed as D
+    idx = np.arange(1003)
+    parts = [idx[D.shard_slice(1003, r, 8)] for r in range(8)]
+    assert np.array_equal(np.concatenate(parts), idx)
+    assert [len(p) for p in parts] == [D.shard_count(1003, r, 8) for r in range(8)]
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_bench_self_launcher_forms_a_group(nproc):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts N rank processes itself (the parent
+    only waits); here the ranks form a gloo group on CPU and report their coordinates, the engine is not imported."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--launch-check"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["rank"])
+    assert [(d["rank"], d["world"], d["local_rank"]) for d in rows] == [(i, nproc, i) for i in range(nproc)]
+    assert all(d["sum"] == nproc * (nproc + 1) / 2 for d in rows)
+
+
+def test_launcher_reports_a_failing_rank():
+    from semiclassical_amd import distributed as D
+    script = os.path.join(ROOT, "tests", "_rank_fail.py")
+    assert D.launch_local_ranks([script], 2, timeout=120) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,tol", [("hk_as5_chi002", 1e-9), ("hk_as60", 1e-9), ("wm_methylium", 1e-8)])
+def test_two_engine_ranks_on_one_gpu(case, tol, tmp_path):
+    """Two rank processes share cuda:0; each runs the HIP engine on half of the golden initial conditions with the
+    global N as weight, the raw sums are flushed through distributed.flush_correlations (gloo) and must reproduce the
+    single-process golden C_auto / k_ic (cli.py:453-458 normalisation)."""
+    from semiclassical_amd import distributed as D
+    g = cases.load(case)
+    nt = min(12, len(g["cauto"]))
+    out = str(tmp_path / "flush.npz")
+    rc = D.launch_local_ranks([os.path.join(ROOT, "tests", "_rank_engine.py"), case, str(nt), out], 2, timeout=600,
+                              extra_env={"SC_DIST_BACKEND": "gloo", "SC_TEST_DEVICE": "0"})
+    if rc != 0 and not os.path.exists(out):
+        pytest.fail(f"rank processes failed with exit code {rc}")
+    r = np.load(out)
+    assert int(r["world"]) == 2 and str(r["backend"]) == "gloo"
+    assert cases.rel_err(r["cauto"], g["cauto"][:nt]) < tol
+    assert cases.rel_err(r["kic"], g["kic"][:nt]) < tol

@@ -1,0 +1,124 @@
+"""Energy-guard VALUE parity, tracker bookkeeping and argument validation of the propagator API (GPU).
+
+The reference's guard compares <T+V> evaluated at the k4 STAGE point of consecutive steps (propagators.py:380,
+385-398, quirk Q2 of SURVEY.md) -- not the energy of the accepted state.  The engine forms that mean on the device
+(`sc_energy_guard`); here its value is compared with the oracle's `eom.en_mean` step by step, on every path that
+produces it: the separable fast kernels (256-thread and one-wavefront variants), the fused dense-potential kernel
+(HK and WM), the unfused generic path and the sGDML stage kernels.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _energies(g, nsteps, pot=None, orc_pot=None):
+    from tests.engine_cases import engine_potential, engine_propagator
+    pot = engine_potential(g) if pot is None else pot
+    orc_pot = cases.oracle_potential(g) if orc_pot is None else orc_pot
+    prop, ref = engine_propagator(g), cases.oracle_propagator(g)
+    got, want = [], []
+    for _ in range(nsteps):
+        prop.step(pot, float(g["dt"]))
+        ref.step(orc_pot, float(g["dt"]))
+        got.append(prop.mean_energy())
+        want.append(float(ref.eom.en_mean))
+    return np.array(got), np.array(want)
+
+
+@pytest.mark.parametrize("name", ["hk_as5_chi002", "hk_as60", "hk_methylium", "wm_methylium", "hk_1d"])
+def test_guard_mean_energy_matches_oracle_k4_stage_value(name):
+    g = cases.load(name)
+    got, want = _energies(g, 6)
+    assert np.max(np.abs(got - want)) < 1e-11 * max(1.0, np.max(np.abs(want))), (got, want)
+    # quirk Q2: the k4-stage mean differs from the mean energy of the accepted state (checked on the oracle itself)
+    assert np.all(np.isfinite(got))
+
+
+def test_guard_mean_energy_generic_and_gdml_paths():
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import propagators as PR
+    from tests.test_generic_potential_gpu import CoupledQuarticPotential
+    rng = np.random.default_rng(5)
+    D, n, dt = 5, 96, 1.5
+    omega = torch.from_numpy(np.sort(rng.uniform(700, 2600, D)) / 219474.63)
+    masses = torch.from_numpy(rng.uniform(0.8, 1.6, D))
+    pot = CoupledQuarticPotential(omega, 2.0e-6, masses, torch.from_numpy(rng.normal(0, 1e-3, D)))
+    q0 = torch.from_numpy(rng.uniform(-6.0, 6.0, D))
+    G = torch.diag(omega * masses)
+    ref, prop = orc.HKOracle(G, G), PR.HermanKlukPropagator(G, G, device="cuda")
+    torch.manual_seed(3)
+    ref.initial_conditions(q0, 0.0 * q0, G, ntraj=n)
+    prop.set_initial_conditions(q0, 0.0 * q0, G, ref.zi, ref.probi)
+    for _ in range(4):
+        prop.step(pot, dt)
+        ref.step(pot, dt)
+        assert abs(prop.mean_energy() - float(ref.eom.en_mean)) < 1e-11 * max(1.0, abs(float(ref.eom.en_mean)))
+    g = cases.load("hk_coumarin_gdml")
+    got, want = _energies(g, 2)
+    assert np.max(np.abs(got - want)) < 1e-9 * max(1.0, np.max(np.abs(want)))
+
+
+def test_sign_trackers_dict_mirrors_reference_bookkeeping():
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load("wm_methylium")
+    prop, pot = engine_propagator(g), engine_potential(g)
+    for _ in range(10):
+        prop.step(pot, float(g["dt"]))
+    tr = prop.sign_trackers
+    assert set(tr) == {"prefactorC", "detA", "detM"}
+    assert np.array_equal(tr["detA"]["signs"].cpu().numpy(), g["signsA_10"])
+    assert np.array_equal(tr["detM"]["signs"].cpu().numpy(), g["signsM_10"])
+    assert np.array_equal(tr["prefactorC"]["signs"].cpu().numpy(), g["signs_10"])
+    assert cases.rel_err(tr["detA"]["previous"].cpu().numpy(), g["detA"][10]) < 1e-8
+    assert cases.rel_err(tr["prefactorC"]["previous"].cpu().numpy(), g["c2"][10]) < 1e-9
+    with pytest.raises(KeyError):
+        prop._get_signs_of_sqrt("nothing")
+    hk = engine_propagator(cases.load("hk_as5_chi002"))
+    assert set(hk.sign_trackers) == {"prefactorC"}
+
+
+def test_run_refuses_malformed_slot_buffers():
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load("hk_as5_chi002")
+    prop, pot = engine_propagator(g), engine_potential(g)
+    dt = float(g["dt"])
+    bad = [torch.zeros((3, 5), dtype=torch.float64, device="cuda"),                      # too short
+           torch.zeros((8, 5), dtype=torch.float32, device="cuda"),                      # wrong dtype
+           torch.zeros((8, 10), dtype=torch.float64, device="cuda")[:, ::2],             # strided
+           torch.zeros((8, 4), dtype=torch.float64, device="cuda"),                      # wrong width
+           torch.zeros((8, 5), dtype=torch.float64)]                                     # host memory
+    for slots in bad:
+        with pytest.raises(ValueError, match="slots has to be"):
+            prop.run(pot, dt, 4, 0.0, slots=slots)
+    ok = torch.zeros((8, 5), dtype=torch.float64, device="cuda")
+    assert prop.run(pot, dt, 4, 0.0, slots=ok) is None
+
+
+def test_constants_follow_in_place_changes_of_the_potential():
+    """caches are keyed on the potential object AND the content of its constants: a coupling vector or a
+    frequency changed in place must reach the device at the next call"""
+    from tests.engine_cases import engine_potential, engine_propagator
+    from oracle import sc_oracle as orc
+    g = cases.load("hk_as5_chi002")
+    dt, E0 = float(g["dt"]), float(g["E0"])
+    pot = engine_potential(g)
+    prop = engine_propagator(g)
+    prop.run(pot, dt, 2, E0)
+    # same object, new coupling vector and new frequencies
+    pot.nac.mul_(3.0)
+    omega2 = cases.T(g["omega"]) * 1.1
+    pot.omega, pot.a, pot.D = omega2, torch.sqrt(2 * omega2 * pot.chi), 0.25 * omega2 / pot.chi
+    prop2 = engine_propagator(g)
+    c, k = prop2.run(pot, dt, 6, E0)
+    ref = cases.oracle_propagator(g)
+    rc, rk = orc.run_loop(ref, orc.MorseOracle(omega2, cases.T(g["chi"]), cases.T(g["nac"]) * 3.0), dt, 6, E0)
+    assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-9
+    # and the propagator that already cached the old constants picks the new ones up as well
+    prop.set_initial_conditions(cases.T(g["q0"]), cases.T(g["p0"]), cases.T(g["Gamma_0"]), cases.T(g["zi"]),
+                                cases.T(g["probi"]))
+    c, k = prop.run(pot, dt, 6, E0)
+    assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-9

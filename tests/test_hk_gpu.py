@@ -209,17 +209,6 @@ def test_weak_pivot_fallback():
     assert int(prop._flags[-1].item()) == prop.ntraj           # ... which was needed for every trajectory
 
 
-def test_row_wave_variant_matches_golden(monkeypatch):
-    """the alternative fast-path layout (SC_FAST_KERNEL=rw: lane = column, full column pivoting) gives the same numbers"""
-    from tests.engine_cases import engine_potential, engine_propagator
-    monkeypatch.setenv("SC_FAST_KERNEL", "rw")
-    for name in ("hk_as60_dt20", "hk_as5_chi002"):
-        g = cases.load(name)
-        prop = engine_propagator(g)
-        cauto, kic = prop.run(engine_potential(g), float(g["dt"]), int(g["nt"]), float(g["E0"]))
-        assert cases.rel_err(cauto, g["cauto"]) < TOL and cases.rel_err(kic, g["kic"]) < TOL
-
-
 def test_unsupported_sizes_fail_loudly():
     """no silent fallback: what the kernels cannot hold is refused with the C-ABI's error text"""
     from semiclassical_amd import propagators as PR

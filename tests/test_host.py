@@ -81,13 +81,34 @@ def test_library_exports_every_declared_symbol():
     so = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert _lib.lib.sc_version() >= 1
+    assert _lib.lib.sc_version() >= 2
+    assert _lib.lib.sc_abi_version() == _lib.ABI_VERSION
+    assert int(re.search(r"#define SC_ABI_VERSION\s+(\d+)", header).group(1)) == _lib.ABI_VERSION
+    for st in _lib.STRUCTS:
+        assert _lib.lib.sc_struct_size(st.__name__.encode()) == ctypes.sizeof(st), st.__name__
+    assert _lib.lib.sc_struct_size(b"no_such_struct") == -1
     # struct sizes agree with the C layout (LP64): a mismatch would shift every pointer
     assert ctypes.sizeof(_lib.sc_state) == 8 + 4 + 4 + 7 * 8
     assert ctypes.sizeof(_lib.sc_potential) == 4 + 4 + 3 * 8 + 8 + 8
     assert ctypes.sizeof(_lib.sc_hk_consts) == 16 + 6 * 8
     assert ctypes.sizeof(_lib.sc_overlap_consts) == 8 + 5 * 8 + 8
     assert ctypes.sizeof(_lib.sc_nac_consts) == 8 + 4 * 8 + 16
+
+
+def test_product_library_reads_no_environment():
+    """the product build has no experiment knobs: it does not even import getenv (those live behind -DSC_TUNING)"""
+    import subprocess
+    from semiclassical_amd import _lib
+    assert _lib.lib.sc_tuning_build() == 0
+    if os.environ.get("SC_LIB_PATH"):
+        pytest.skip("a variant library is loaded")
+    import shutil
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("nm not available")
+    out = subprocess.run([nm, "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0 and "hipLaunchKernel" in out.stdout
+    assert "getenv" not in out.stdout
 
 
 def test_no_cpu_path():
