@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        2
+#define SC_ABI_VERSION        3
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -132,6 +132,10 @@ typedef struct sc_wm_consts {
      *   dvec_out [n][D] complex      C_qQ^T (q0 - q) + i/hbar PI_Q, :1513 */
     double pre_coef;
     double *coef_out, *cqq_out, *dvec_out;
+    /* matrix storage for shapes whose per-trajectory matrices exceed the LDS of a compute unit (D >~ 24 at full
+     * rank): sc_wm_scratch_bytes(n, D, d') bytes of device memory, 0 / NULL when not needed.  Contents are scratch. */
+    double *scratch;
+    int64_t scratch_bytes;
 } sc_wm_consts;
 
 /* sGDML force field, reference semiclassical/gdml_predictor.py:57-85 (constructor) and :96-250 (forward).
@@ -210,8 +214,11 @@ int sc_reduce_slot(const double *corr_partials, int32_t n_corr, const double *en
  *   track: 2 initialise the trackers (t = 0), 1 track against the previous step, 0 recompute with the stored signs
  *   has_nac == 0: k_ic terms are skipped (wc->n1 etc. may be NULL)
  *   cq_out/kq_out complex [n] may be NULL; partials[sc_wm_grid()][4] as in sc_hk_correlate.
- * Limits: every matrix of one trajectory lives in LDS, D <= ~24 at full rank (SC_ERR_UNSUPPORTED beyond). */
+ * Three kernels behind it: a register-resident one (D <= 16, e <= 16 at the instantiated shapes), one with every matrix of
+ * the trajectory in LDS, and the same with the matrices in wc->scratch for shapes beyond the LDS (no size limit other
+ * than memory: sc_wm_scratch_bytes says how much scratch the call needs, 0 if none, -1 for invalid shapes). */
 int sc_wm_grid(int64_t n, int32_t dim);
+int64_t sc_wm_scratch_bytes(int64_t n, int32_t dim, int32_t dprime);
 int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi, const double *probi,
                     double mc_norm, int32_t track, int32_t has_nac, double *cq_out, double *kq_out,
                     double *partials, void *stream);

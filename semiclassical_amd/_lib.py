@@ -51,7 +51,8 @@ class sc_wm_consts(C.Structure):
                 ("inv_scale_a", C.c_double), ("inv_two_pi", C.c_double), ("pre", C.c_double),
                 ("p0n1", C.c_double), ("n2", C.c_double),
                 ("detA", c_double_p), ("detM", c_double_p), ("sgnA", c_double_p), ("sgnM", c_double_p),
-                ("pre_coef", C.c_double), ("coef_out", c_double_p), ("cqq_out", c_double_p), ("dvec_out", c_double_p)]
+                ("pre_coef", C.c_double), ("coef_out", c_double_p), ("cqq_out", c_double_p), ("dvec_out", c_double_p),
+                ("scratch", c_double_p), ("scratch_bytes", C.c_int64)]
 
 
 class sc_gdml_model(C.Structure):
@@ -69,7 +70,7 @@ SC_POT_MORSE, SC_POT_HARMONIC_SEP, SC_POT_EPS_MORSE, SC_POT_HARMONIC_DENSE = 1, 
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 2              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 3              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 
@@ -91,6 +92,7 @@ SIGNATURES = {
                                   c_double_p, C.c_double, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     "sc_energy_guard": (C.c_int, [c_double_p, C.c_int32, C.c_double, c_double_p, C.c_void_p]),
     "sc_wm_grid": (C.c_int, [C.c_int64, C.c_int32]),
+    "sc_wm_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "sc_wm_correlate": (C.c_int, [P(sc_state), P(sc_wm_consts), c_double_p, c_double_p, C.c_double, C.c_int32,
                                   C.c_int32, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     "sc_wm_grid_sum": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32, c_double_p,

@@ -18,24 +18,19 @@
 //     determinants detA, detM the reference takes of the same scaled matrices (:1328-1332, 1358-1359);
 //   * Rqq, RQQ, RqQ, Pq, PQ are never formed: eqn (85)/(100) only need their contractions with dq = q0-q, dQ = q0-Q and
 //     n1, i.e. bilinear forms a^T iM b with a, b in { CqQ^T dq, CqQ^T n1, G0 dQ, G0 n1, PIQ - p0 }.
-#include "sc_common.h"
+//
+// Three mappings of this arithmetic exist (sc_wm_correlate picks one):
+//   wm_small_kernel<D, d'>  (sc_wm_small.hip)  D <= 16, e <= 16 at the instantiated shapes: registers + DPP
+//   wm_kernel<false>        every matrix of the trajectory in LDS (one workgroup per trajectory)
+//   wm_kernel<true>         the same code with the matrices in a per-workgroup block of GLOBAL memory (L2 / MALL
+//                           resident scratch supplied by the caller) for shapes whose matrices exceed the 160 KB of LDS
+#include "sc_wm.h"
 
 namespace {
 
-struct WmArgs {
-    sc_state st;
-    sc_wm_consts wc;
-    const double *zi, *probi;
-    double mc_norm;
-    int track;          // 0: use the stored branch signs, 1: track against the previous determinants, 2: initialise
-    int has_nac;
-    int stage_consts;   // copy the D x D constants into LDS once per workgroup (when they fit)
-    double *cq_out, *kq_out, *partials;
-};
-
 // Gauss-Jordan inversion of the n x n complex matrix in the left half of aug (n x 2n, row-major); the right half must
 // hold the identity on entry and holds the inverse on exit.  Returns det(left) to every thread.  colbuf: n complex.
-__device__ cplx lds_gauss_jordan(cplx *aug, int n, cplx *colbuf, int *ipiv) {
+__device__ __forceinline__ cplx lds_gauss_jordan(cplx *aug, int n, cplx *colbuf, int *ipiv) {
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, w2 = 2 * n;
     cplx det = c_make(1.0, 0.0);
     for (int k = 0; k < n; ++k) {
@@ -79,18 +74,6 @@ __device__ cplx lds_gauss_jordan(cplx *aug, int n, cplx *colbuf, int *ipiv) {
     return det;
 }
 
-// branch tracker of sqrt(z(t)), reference propagators.py:1006-1052; returns the sign to use now
-__device__ __forceinline__ double track_sign(int track, cplx z, cplx *prev, double *sgn) {
-    double s = *sgn;
-    if (track == 2) { s = 1.0; *sgn = s; *prev = z; }
-    else if (track == 1) {
-        const cplx z1 = *prev;
-        if (z1.x < 0.0 && z.x < 0.0 && z1.y * z.y < 0.0) s = -s;
-        *sgn = s; *prev = z;
-    }
-    return s;
-}
-
 // sizes of the shared LDS regions of wm_kernel (doubles / complex values), see the carve-up there
 __host__ __device__ inline size_t wm_region_p(int D, int dp) {
     const size_t E = 2 * (size_t)dp, a = 3 * (size_t)D * E + E * E, b = 2 * (size_t)D * D + 4 * (size_t)dp * dp + 20 * (size_t)dp;
@@ -102,6 +85,7 @@ __host__ __device__ inline size_t wm_region_q(int D, int dp) {
     return a > b ? a : b;
 }
 
+template <bool GLOBAL_SCRATCH>
 __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     extern __shared__ double2 smem2[];
     __shared__ double red[32];
@@ -114,7 +98,9 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     //   region P: {Mq', Mp', Gamma_t Mq', Mp'^T Mq'} (dead once A' and BQ' exist) -> Wm = BQ' iA' (dead once Gt, Gti
     //             exist) -> {V, [M'|I], hat, rho}
     //   region Q: [A'/s | I] (dead once Wm exists) -> {Gt (later CQQ), Gti}
-    double *f = (double *)smem2;
+    // GLOBAL_SCRATCH: the same carve-up inside this workgroup's block of the caller's scratch buffer.  The waves of a
+    // workgroup share one CU and its write-through L1, so __syncthreads() orders these global accesses as it orders LDS.
+    double *f = GLOBAL_SCRATCH ? (double *)((char *)A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (double *)smem2;
     double *vec = f;             f += 8 * D;        // dq, dQ, dp, g, s_dq, w_dQ, (2 spare)
     double *rowtmp = f;          f += 3 * D + (D & 1);   // per-row partial results of the scalar tail (3 x D)
     double *P = f;               f += wm_region_p(D, dp);
@@ -342,8 +328,8 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             ex = c_add(ex, c_mul(c_make(0.0, ihb), PQ_dQ));
             // branch-tracked square roots
             cplx *prevA = (cplx *)A.wc.detA + tr, *prevM = (cplx *)A.wc.detM + tr;
-            const double sA = track_sign(A.track, detA, prevA, A.wc.sgnA + tr);
-            const double sM = track_sign(A.track, detM, prevM, A.wc.sgnM + tr);
+            const double sA = wm_track_sign(A.track, detA, prevA, A.wc.sgnA + tr);
+            const double sM = wm_track_sign(A.track, detM, prevM, A.wc.sgnM + tr);
             const cplx cpre = c_scale(c_sqrt(((const cplx *)A.st.c2)[tr]), A.st.sgn[tr]);
             cplx pre = c_mul(cpre, c_exp(c_make(0.0, A.st.act[tr] * ihb)));
             pre = c_mul(pre, c_scale(c_inv(c_sqrt(detA)), sA));
@@ -379,6 +365,9 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     }
     (void)red;
     if (tid == 0) for (int i = 0; i < 4; ++i) A.partials[(size_t)blockIdx.x * 4 + i] = acc[i];
+    // fewer workgroups than partial-sum slots (scratch-limited grid): the first workgroup clears the rest
+    if (blockIdx.x == 0)
+        for (int i = 4 * (int)gridDim.x + tid; i < 4 * A.npartials; i += nth) A.partials[i] = 0.0;
 }
 
 size_t wm_lds_bytes(int D, int dp) {
@@ -563,24 +552,53 @@ extern "C" int sc_wm_grid(int64_t n, int32_t dim) {
     return (int)(n < 2048 ? (n > 0 ? n : 1) : 2048);
 }
 
+// workgroups of the global-scratch variant: bounded so that the scratch stays within a few hundred MB
+static int wm_scratch_grid(int64_t n) { return (int)(n < 512 ? (n > 0 ? n : 1) : 512); }
+static size_t wm_scratch_stride(int D, int dp) { return (wm_lds_bytes(D, dp) + 255) & ~(size_t)255; }
+static bool wm_has_small_kernel(int D, int dp) {
+    return (D == dp && D >= 1 && D <= 8) || (D == 9 && dp == 3) || (D == 12 && dp == 6);
+}
+
+extern "C" int64_t sc_wm_scratch_bytes(int64_t n, int32_t dim, int32_t dprime) {
+    if (dim < 1 || dprime < 1 || dprime > dim) return -1;
+    if (wm_has_small_kernel(dim, dprime) || wm_lds_bytes(dim, dprime) <= 160 * 1024) return 0;
+    return (int64_t)wm_scratch_stride(dim, dprime) * wm_scratch_grid(n);
+}
+
 extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi, const double *probi,
                                double mc_norm, int32_t track, int32_t has_nac, double *cq_out, double *kq_out,
                                double *partials, void *stream) {
     if (!st || !wc || !zi || !probi || !partials) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: null argument");
     if (wc->dim != st->dim) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: dimension mismatch");
+    if (wc->dprime < 1 || wc->dprime > st->dim) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: d' outside 1..D");
     if (st->n <= 0) return SC_OK;
-    size_t lds = wm_lds_bytes(st->dim, wc->dprime);
-    const int stage_consts = lds + wm_const_bytes(st->dim, wc->dprime) <= 64 * 1024;   // keep >= 2 workgroups per CU
-    if (stage_consts) lds += wm_const_bytes(st->dim, wc->dprime);
-    if (lds > 160 * 1024)
-        return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_correlate: D=%d d'=%d needs %zu B of LDS per trajectory (limit 160 KiB)",
-                       st->dim, wc->dprime, lds);
+    const int D = st->dim, dp = wc->dprime, grid = sc_wm_grid(st->n, D);
     WmArgs a;
-    a.st = *st; a.wc = *wc; a.zi = zi; a.probi = probi; a.mc_norm = mc_norm; a.track = track; a.has_nac = has_nac; a.stage_consts = stage_consts;
-    a.cq_out = cq_out; a.kq_out = kq_out; a.partials = partials;
-    if (hipFuncSetAttribute((const void *)wm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    a.st = *st; a.wc = *wc; a.zi = zi; a.probi = probi; a.mc_norm = mc_norm; a.track = track; a.has_nac = has_nac;
+    a.stage_consts = 0; a.cq_out = cq_out; a.kq_out = kq_out; a.partials = partials;
+    a.scratch = nullptr; a.scratch_stride = 0; a.npartials = grid;
+    hipStream_t s = (hipStream_t)stream;
+    if (wm_has_small_kernel(D, dp)) {
+        const int rc = sc_wm_launch_small(a, grid, s);
+        if (rc != 0) return rc < 0 ? rc : SC_OK;
+    }
+    size_t lds = wm_lds_bytes(D, dp);
+    if (lds > 160 * 1024) {
+        // the matrices of one trajectory do not fit LDS: run the same kernel on the caller's scratch block
+        const int gs = wm_scratch_grid(st->n);
+        const size_t stride = wm_scratch_stride(D, dp);
+        if (!wc->scratch || wc->scratch_bytes < (int64_t)(stride * gs))
+            return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: D=%d d'=%d needs a scratch buffer of %zu B "
+                           "(sc_wm_scratch_bytes), got %lld", D, dp, stride * gs, (long long)wc->scratch_bytes);
+        a.scratch = wc->scratch; a.scratch_stride = stride;
+        hipLaunchKernelGGL(wm_kernel<true>, dim3(gs), dim3(256), 0, s, a);
+        return sc_check_launch("sc_wm_correlate (global scratch)");
+    }
+    a.stage_consts = lds + wm_const_bytes(D, dp) <= 64 * 1024;   // keep >= 2 workgroups per CU
+    if (a.stage_consts) lds += wm_const_bytes(D, dp);
+    if (hipFuncSetAttribute((const void *)wm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sc_check_launch("sc_wm_correlate (LDS attribute)");
-    const int threads = st->dim <= 16 ? 64 : 256;
-    hipLaunchKernelGGL(wm_kernel, dim3(sc_wm_grid(st->n, st->dim)), dim3(threads), lds, (hipStream_t)stream, a);
+    const int threads = D <= 16 ? 64 : 256;
+    hipLaunchKernelGGL(wm_kernel<false>, dim3(grid), dim3(threads), lds, s, a);
     return sc_check_launch("sc_wm_correlate");
 }

@@ -597,8 +597,8 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
 
     ``alpha``, ``beta``: widths of the phase-space cell over which the HK integrand is integrated out.
     The Filinov matrix, its inverse / determinant, the second inverse / determinant and the terms of
-    eqns (85) and (100) are evaluated per trajectory by ``sc_wm_correlate`` right after the HK step kernel.
-    All matrices of one trajectory are held in LDS, which limits this round's kernel to D <~ 24 at full rank.
+    eqns (85) and (100) are evaluated per trajectory by ``sc_wm_correlate`` right after the HK step kernel
+    (registers for small matrices, LDS for medium ones, an L2-resident scratch block beyond that: no size limit).
     """
 
     def __init__(self, Gamma_i, Gamma_t, alpha, beta, device='cuda'):
@@ -623,6 +623,9 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         self._wm_step, self._wm_has_nac = -1, False
         self._wm_export_step = -1
         self._wm_nac_bufs = None
+        need = lib.sc_wm_scratch_bytes(n, self.dim, wm.dprime)      # 0 while the matrices of a trajectory fit on chip
+        assert need >= 0
+        self._wm_scratch = torch.empty(need // 8, dtype=F64, device=dev) if need > 0 else None
         self._build_wm_struct()
 
     def _build_wm_struct(self):
@@ -634,7 +637,8 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
             inv_scale_a=wm.inv_scale_a, inv_two_pi=wm.inv_two_pi, pre=wm.pre,
             p0n1=self._wm_p0n1 if nb else 0.0, n2=self._wm_n2 if nb else 0.0,
             detA=ptr(self._detA), detM=ptr(self._detM), sgnA=ptr(self._sgnA), sgnM=ptr(self._sgnM),
-            pre_coef=wm.pre_coef)
+            pre_coef=wm.pre_coef, scratch=ptr(self._wm_scratch),
+            scratch_bytes=0 if self._wm_scratch is None else self._wm_scratch.numel() * 8)
 
     def _remember_nac(self, potential):
         current, fp = self._nac_is_current(potential)

@@ -85,3 +85,70 @@ def test_wm_norm_of_many_trajectories_is_one():
     for _ in range(20):
         prop.step(pot, float(g["dt"]))
     assert abs(prop.norm() - 1.0) < 0.05
+
+
+def _wm_vs_oracle(D, zero_modes, n, nt, seed, dense_gamma, alpha=60.0):
+    """fresh seeded inputs, anharmonic AS potential of D modes; width matrices diagonal or rotated / rank deficient"""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(seed)
+    omega = torch.from_numpy(np.sort(rng.uniform(600, 2500, D)) / 219474.63)
+    S = torch.from_numpy(rng.uniform(0.05, 0.3, D) * rng.choice([-1, 1], D))
+    nac = torch.from_numpy(rng.normal(0, 1e-3, D))
+    chi = torch.full((D,), 0.01)
+    q0 = torch.sqrt(2 * abs(S) / omega) * torch.sign(S)
+    p0 = 0.0 * q0
+    if dense_gamma:
+        Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        w = omega.numpy() * rng.uniform(0.7, 1.4, D)
+        w[:zero_modes] = 0.0
+        G = torch.from_numpy(Q @ np.diag(w) @ Q.T)
+        G = 0.5 * (G + G.T)
+    else:
+        G = torch.diag(omega)
+    E0, dt = float(0.5 * omega.sum()), 3.0
+    ref = orc.WMOracle(G, G, alpha, alpha)
+    prop = PR.WaltonManolopoulosPropagator(G, G, alpha, alpha, device="cuda")
+    torch.manual_seed(seed)
+    ref.initial_conditions(q0, p0, G, ntraj=n)
+    rc, rk = orc.run_loop(ref, orc.MorseOracle(omega, chi.clone(), nac), dt, nt, E0)
+    prop.set_initial_conditions(q0, p0, G, ref.zi, ref.probi)
+    assert prop._wm_host.dprime == D - zero_modes
+    c, k = prop.run(P.MorsePotential(omega, chi.clone(), nac), dt, nt, E0)
+    for key, sgn in (("detA", prop._sgnA), ("detM", prop._sgnM), ("prefactorC", prop._sgn)):      # trackers bit-exact
+        assert np.array_equal(cnp(sgn), ref.tracker.signs(key).real.numpy()), key
+    return cases.rel_err(c, rc), cases.rel_err(k, rk), prop
+
+
+@pytest.mark.parametrize("D,zero_modes", [(2, 0), (3, 0), (4, 0), (6, 0), (7, 0), (8, 0), (9, 6), (12, 6)])
+def test_wm_register_kernel_shapes(D, zero_modes):
+    """every instantiated shape of the register-resident kernel (sc_wm_small.hip), dense width matrices, ragged n"""
+    ec, ek, _ = _wm_vs_oracle(D, zero_modes, n=150, nt=10, seed=40 + D, dense_gamma=True)
+    assert ec < TOL and ek < TOL, (ec, ek)
+
+
+@pytest.mark.parametrize("D,zero_modes", [(10, 0), (11, 4), (20, 0)])
+def test_wm_lds_kernel_shapes(D, zero_modes):
+    """shapes without a register-resident instantiation take the LDS kernel"""
+    ec, ek, _ = _wm_vs_oracle(D, zero_modes, n=70, nt=8, seed=60 + D, dense_gamma=True)
+    assert ec < TOL and ek < TOL, (ec, ek)
+
+
+@pytest.mark.parametrize("D", [32, 60])
+def test_wm_beyond_lds_runs_on_global_scratch(D):
+    """WM on a 60-mode model (the size of BASELINE configs[1]): the matrices of a trajectory exceed the LDS, the same
+    kernel runs on the caller's scratch block -- no size limit, as in the reference (propagators.py:1195-1389)"""
+    from semiclassical_amd._lib import lib
+    assert lib.sc_wm_scratch_bytes(24, D, D) > 0
+    ec, ek, prop = _wm_vs_oracle(D, 0, n=24, nt=5, seed=80 + D, dense_gamma=False, alpha=200.0)
+    assert prop._wm_scratch is not None
+    assert ec < TOL and ek < TOL, (ec, ek)
+
+
+def test_wm_scratch_query_and_refusal():
+    from semiclassical_amd._lib import lib
+    assert lib.sc_wm_scratch_bytes(1000, 12, 6) == 0          # register kernel
+    assert lib.sc_wm_scratch_bytes(1000, 20, 20) == 0         # LDS kernel
+    assert lib.sc_wm_scratch_bytes(1000, 60, 60) > 0
+    assert lib.sc_wm_scratch_bytes(1000, 5, 6) == -1
