@@ -97,14 +97,17 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // Gauss-Jordan elimination of the N x N complex system held one ROW per lane (lane i: a[0..N) and NR right-hand
 // sides b[0..NR)); rows >= N must be zero and enter with used = true.  Partial pivoting over the unused LANES for
-// column k.  On exit the lane that was the pivot of step k (`myk` = k) holds row k of the solution in b; `src` of
-// lane k is the byte address (ds_bpermute) of that lane; det = determinant of the matrix.
+// column k.  Rows are not normalised while eliminating: a lane subtracts m = a_ik / pivot times the pivot row, the
+// pivot lane itself takes m = 0 (one select per step instead of one per element), and at the end every lane divides
+// its right-hand sides by its own pivot.  On exit the lane that was the pivot of step k (`myk` = k) holds row k of
+// the solution in b; `src` of lane k is the byte address (ds_bpermute) of that lane; det = determinant of the matrix.
 template <int N, int NR>
 __device__ __forceinline__ void gauss_jordan_rows(cplx (&a)[N], cplx (&b)[NR], bool used, int r, int rowbase, int &myk,
                                                   int &src, cplx &det) {
     det = c_make(1.0, 0.0);
     int parity = 0;
     bool singular = false;
+    cplx myinv = c_make(0.0, 0.0);
     myk = r;
     src = (rowbase | r) << 2;
     sfor_bb<0, N>([&](auto kc) {
@@ -120,23 +123,22 @@ __device__ __forceinline__ void gauss_jordan_rows(cplx (&a)[N], cplx (&b)[NR], b
         singular = singular || (piv.x == 0.0 && piv.y == 0.0);
         det = c_mul(det, piv);
         const cplx inv = c_inv(piv);
-        const cplx f = a[k];
         const bool me = r == p;
+        const cplx f = c_mul(a[k], inv);
+        const cplx m = c_make(me ? 0.0 : f.x, me ? 0.0 : f.y);
         sfor<k + 1, N>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            const cplx pr = c_mul(perm(addr, a[j]), inv);
-            const cplx upd = c_fnma(f, pr, a[j]);
-            a[j] = c_make(me ? pr.x : upd.x, me ? pr.y : upd.y);
+            a[j] = c_fnma(m, perm(addr, a[j]), a[j]);
         });
         sfor<0, NR>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            const cplx pr = c_mul(perm(addr, b[j]), inv);
-            const cplx upd = c_fnma(f, pr, b[j]);
-            b[j] = c_make(me ? pr.x : upd.x, me ? pr.y : upd.y);
+            b[j] = c_fnma(m, perm(addr, b[j]), b[j]);
         });
-        if (me) { used = true; myk = k; }
+        if (me) { used = true; myk = k; myinv = inv; }
         if (r == k) src = addr;
     });
+#pragma unroll
+    for (int j = 0; j < NR; ++j) b[j] = c_mul(b[j], myinv);
     if (parity) det = c_make(-det.x, -det.y);
     if (singular) det = c_make(0.0, 0.0);
 }
@@ -149,12 +151,17 @@ struct WmSmallLayout {
                                    + 16 * D          // UT[i][a] = U[a][i], zero for i >= d'
                                    + 2 * 16 * E      // CstT[i][j] = Cst[j][i] (complex), zero for i >= e
                                    + 8 * 16;         // q0, p0, n1, s_n1, w_n1, crow = Cqq n1, 2 spare
-    static constexpr int xbuf = D * EP;              // complex values per trajectory
+    static constexpr int H = (D + 1) / 2;            // rows per half of the Wm exchange
+    static constexpr int xh = H * EP;                // complex: transposition buffer (D x EP reals fit as well)
+    static constexpr int xq = (E > D ? E : D) * D;   // complex: BQ'^T (e x D), later the rows of Gti (D x D)
+    static constexpr int xbuf = xh + xq;             // complex values per trajectory
     static constexpr size_t bytes = (size_t)n_const * 8 + (size_t)16 * xbuf * 16 + 16 * 4 * 8;
 };
 
 #ifndef SC_WM_SMALL_OCC
-#define SC_WM_SMALL_OCC 2      // waves per SIMD the kernel is compiled for (register budget 512 / OCC)
+// waves per SIMD the kernel is compiled for (register budget 512 / OCC).  Measured on MI355X, methylium (12, 6),
+// n = 1e5: 1 -> 1.37 ms (the allocator parks idle rows in AGPRs), 2 -> 2.3 .. 2.9 ms (the same rows go to scratch).
+#define SC_WM_SMALL_OCC 1
 #endif
 
 template <int D, int DP>
@@ -167,13 +174,13 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     const double ihb = 1.0 / SC_HBAR;
 
     double *ls = (double *)smem2;
-    double *cGt = ls;   ls += 16 * D;
-    double *cG0 = ls;   ls += 16 * D;
-    double *cCqq = ls;  ls += 16 * D;
-    double *cS = ls;    ls += 16 * D;
-    double *ciG = ls;   ls += 16 * D;
-    double *cUT = ls;   ls += 16 * D;
-    double *cCstT = ls; ls += 2 * 16 * E;
+    double *sGt = ls;   ls += 16 * D;
+    double *sG0 = ls;   ls += 16 * D;
+    double *sCqq = ls;  ls += 16 * D;
+    double *sS = ls;    ls += 16 * D;
+    double *siG = ls;   ls += 16 * D;
+    double *sUT = ls;   ls += 16 * D;
+    double *sCstT = ls; ls += 2 * 16 * E;
     double *cvec = ls;  ls += 8 * 16;            // [q0 | p0 | n1 | s_n1 | w_n1 | crow | - | -][16]
     cplx *xall = (cplx *)ls;
     double *red = (double *)(xall + 16 * L::xbuf);
@@ -182,17 +189,17 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     for (int e = tid; e < 16 * D; e += 256) {
         const int i = e / D, b = e - i * D;
         const bool in = i < D;
-        cGt[e] = in ? W.Gt[i * D + b] : 0.0;
-        cG0[e] = in ? W.G0[i * D + b] : 0.0;
-        cCqq[e] = in ? W.Cqq[i * D + b] : 0.0;
-        cS[e] = in ? W.S[i * D + b] : 0.0;
-        ciG[e] = in ? W.iGi0[i * D + b] : 0.0;
-        cUT[e] = i < DP ? W.U[b * DP + i] : 0.0;
+        sGt[e] = in ? W.Gt[i * D + b] : 0.0;
+        sG0[e] = in ? W.G0[i * D + b] : 0.0;
+        sCqq[e] = in ? W.Cqq[i * D + b] : 0.0;
+        sS[e] = in ? W.S[i * D + b] : 0.0;
+        siG[e] = in ? W.iGi0[i * D + b] : 0.0;
+        sUT[e] = i < DP ? W.U[b * DP + i] : 0.0;
     }
     for (int e = tid; e < 16 * E; e += 256) {
         const int i = e / E, j = e - i * E;
-        cCstT[2 * e] = i < E ? W.Cst[2 * (j * E + i)] : 0.0;
-        cCstT[2 * e + 1] = i < E ? W.Cst[2 * (j * E + i) + 1] : 0.0;
+        sCstT[2 * e] = i < E ? W.Cst[2 * (j * E + i)] : 0.0;
+        sCstT[2 * e + 1] = i < E ? W.Cst[2 * (j * E + i) + 1] : 0.0;
     }
     if (tid < 16) {
         const bool in = tid < D, nac = in && A.has_nac;
@@ -209,8 +216,9 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
 
     kptr kU = (kptr)W.U, kGt = (kptr)W.Gt, kiG = (kptr)W.iGi0, kBq = (kptr)W.Bq;
     const double q0r = cvec[r], p0r = cvec[16 + r], n1r = cvec[32 + r], wn1r = cvec[64 + r], crowr = cvec[80 + r];
-    cplx *xc = xall + grp * L::xbuf;        // exchange buffer of this trajectory
+    cplx *xc = xall + grp * L::xbuf;        // exchange buffers of this trajectory: transpositions ...
     double *xr = (double *)xc;
+    cplx *xq = xc + L::xh;                  // ... and group-uniform operands (BQ'^T, then the rows of Gti)
 
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const int64_t n = A.st.n, stride = (int64_t)gridDim.x * 16;
@@ -222,6 +230,11 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
         // the scalar loads of the constants are redone per trajectory next to their use: hoisted out of the loop they
         // would occupy (and spill) several hundred scalar registers
         asm volatile("" : "+s"(kU), "+s"(kGt), "+s"(kiG), "+s"(kBq));
+        // the same for the per-lane rows of the constants in LDS: read where they are used, never kept across phases
+        int lofs = 0;
+        asm volatile("" : "+v"(lofs));
+        const double *cGt = sGt + lofs, *cG0 = sG0 + lofs, *cCqq = sCqq + lofs, *cS = sS + lofs, *ciG = siG + lofs;
+        const double *cUT = sUT + lofs, *cCstT = sCstT + lofs;
 
         // ---- rows of the monodromy blocks; Mq' = [Mqq U, Mqp U], Mp' = [Mpq U, Mpp U] (row r) ----
         double Mq[E], Mp[E];
@@ -240,15 +253,17 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
                 dq = q0r - zi[r]; dpv = p0r - zi[D + r];
             }
 #pragma unroll
-            for (int j = 0; j < DP; ++j) {
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            for (int j = 0; j < E; ++j) { Mq[j] = 0.0; Mp[j] = 0.0; }
+            // one ROW of U (contiguous scalar loads) per block: the scalar registers hold d' constants at a time
+            sfor_bb<0, D>([&](auto bcn) {
+                constexpr int b = decltype(bcn)::value;
 #pragma unroll
-                for (int b = 0; b < D; ++b) {
+                for (int j = 0; j < DP; ++j) {
                     const double u = kU[b * DP + j];
-                    s0 = fma(mqq[b], u, s0); s1 = fma(mqp[b], u, s1); s2 = fma(mpq[b], u, s2); s3 = fma(mpp[b], u, s3);
+                    Mq[j] = fma(mqq[b], u, Mq[j]); Mq[DP + j] = fma(mqp[b], u, Mq[DP + j]);
+                    Mp[j] = fma(mpq[b], u, Mp[j]); Mp[DP + j] = fma(mpp[b], u, Mp[DP + j]);
                 }
-                Mq[j] = s0; Mq[DP + j] = s1; Mp[j] = s2; Mp[DP + j] = s3;
-            }
+            });
         }
         const double dQ = r < D ? q0r - qv : 0.0;
 
@@ -272,15 +287,13 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             for (int a = 0; a < D; ++a) MpT[a] = r < E ? xr[a * EP + r] : 0.0;
             wave_lds_fence();
         }
-        WM_BLOCK {      // in-lane with the constant (symmetric) Gt
+        sfor_bb<0, D>([&](auto ac) {      // in-lane with the constant (symmetric) Gt, one row of it per block
+            constexpr int a = decltype(ac)::value;
+            double s = 0.0;
 #pragma unroll
-            for (int a = 0; a < D; ++a) {
-                double s = 0.0;
-#pragma unroll
-                for (int b = 0; b < D; ++b) s = fma(kGt[a * D + b], MqT[b], s);
-                TqT[a] = s;
-            }
-        }
+            for (int b = 0; b < D; ++b) s = fma(kGt[a * D + b], MqT[b], s);
+            TqT[a] = s;
+        });
 
         // ---- GT[i][j] = G[j][i] first (the last use of Mp' rows and Mq' columns), then G = Mp'^T Mq' (row i) and
         //      ST[i][j] = (Mq'^T Gt Mq')[j][i] ----
@@ -315,6 +328,11 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             }
 #pragma unroll
             for (int a = 0; a < D; ++a) Rh[a] = c_make(TqT[a], ihb * MpT[a]);
+            // BQ'^T also goes to LDS: eqn (57) reads it back as group-uniform operands after the elimination
+            if (r < E) {
+#pragma unroll
+                for (int a = 0; a < D; ++a) xq[r * D + a] = Rh[a];
+            }
         }
 
         int myk, src;
@@ -323,44 +341,45 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
 
         // ---- Wm = BQ' A'^-1: the pivot lane of step k holds Wm[:, k] (scaled by s); write it as column k, read row r ----
         cplx Wm[E];
-        WM_BLOCK {
+        sfor_bb<0, 2>([&](auto hc) {               // two halves of the rows: the exchange buffer holds (D+1)/2 of them
+            constexpr int h0 = decltype(hc)::value ? L::H : 0, h1 = decltype(hc)::value ? D : L::H;
             if (r < E) {
 #pragma unroll
-                for (int a = 0; a < D; ++a) xc[a * EP + myk] = c_scale(Rh[a], W.inv_scale_a);
+                for (int a = h0; a < h1; ++a) xc[(a - h0) * EP + myk] = c_scale(Rh[a], W.inv_scale_a);
             }
             wave_lds_fence();
+            if (r >= h0 && r < h1) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) Wm[k] = r < D ? xc[r * EP + k] : c_make(0.0, 0.0);
+                for (int k = 0; k < E; ++k) Wm[k] = xc[(r - h0) * EP + k];
+            }
             wave_lds_fence();
+        });
+        if (r >= D) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) Wm[k] = c_make(0.0, 0.0);
         }
 
         // ---- Gt~ = Gt - Wm BQ'^T (57) ----
         cplx Gtl[D], Gti[D];
 #pragma unroll
         for (int b = 0; b < D; ++b) Gtl[b] = c_make(cGt[r * D + b], 0.0);
-        sfor_bb<0, 2 * E>([&](auto kc) {          // (k, half of the columns) per block: 12 moves in flight, not 24
-            constexpr int k = decltype(kc)::value / 2, b0 = (decltype(kc)::value & 1) ? (D + 1) / 2 : 0;
-            constexpr int b1 = (decltype(kc)::value & 1) ? D : (D + 1) / 2;
+        sfor_bb<0, E>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
 #pragma unroll
-            for (int b = b0; b < b1; ++b) {
-                const cplx bq = c_make(bc<k>(TqT[b]), ihb * bc<k>(MpT[b]));
-                Gtl[b] = c_fnma(Wm[k], bq, Gtl[b]);
-            }
+            for (int b = 0; b < D; ++b) Gtl[b] = c_fnma(Wm[k], xq[k * D + b], Gtl[b]);
         });
         // ---- Gti = Wm Bq'^T (59);  Bq' = [Gamma_i U | -i/hbar U]: real in its first d' columns, imaginary in the last d'
-        WM_BLOCK {
+        sfor_bb<0, D>([&](auto bcn) {
+            constexpr int b = decltype(bcn)::value;
+            cplx s = c_make(0.0, 0.0);
 #pragma unroll
-            for (int b = 0; b < D; ++b) {
-                cplx s = c_make(0.0, 0.0);
-#pragma unroll
-                for (int k = 0; k < DP; ++k) {
-                    const double br = kBq[2 * (b * E + k)], bi = kBq[2 * (b * E + DP + k) + 1];
-                    s.x = fma(Wm[k].x, br, s.x); s.y = fma(Wm[k].y, br, s.y);
-                    s.x = fma(-Wm[DP + k].y, bi, s.x); s.y = fma(Wm[DP + k].x, bi, s.y);
-                }
-                Gti[b] = s;
+            for (int k = 0; k < DP; ++k) {
+                const double br = kBq[2 * (b * E + k)], bi = kBq[2 * (b * E + DP + k) + 1];
+                s.x = fma(Wm[k].x, br, s.x); s.y = fma(Wm[k].y, br, s.y);
+                s.x = fma(-Wm[DP + k].y, bi, s.x); s.y = fma(Wm[DP + k].x, bi, s.y);
             }
-        }
+            Gti[b] = s;
+        });
 
         // ---- per-trajectory vectors: g = iGi0 (p0 - p_i), s_dq = S dq, w_dQ = G0 dQ, cdq = Cqq dq, g0g = G0 g ----
         double gv = 0.0, sdq = 0.0, wdQ = 0.0, cdq = 0.0, g0g = 0.0;
@@ -386,25 +405,33 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             });
         }
 
-        // ---- V = Gti iGi0 ; CQQ = Gt~ - V Gti^T (70), in place in Gtl ----
+        // ---- V = Gti iGi0 ; CQQ = Gt~ - V Gti^T (70), in place in Gtl.  The rows of Gti go to the exchange buffer and
+        //      come back as group-uniform (broadcast) LDS reads: their registers are free while the product runs ----
         {
             cplx V[D];
+            sfor_bb<0, D>([&](auto bcn) {          // iGi0 is symmetric: column b = row b, contiguous scalar loads
+                constexpr int b = decltype(bcn)::value;
+                cplx s = c_make(0.0, 0.0);
+#pragma unroll
+                for (int k = 0; k < D; ++k) { const double x = kiG[b * D + k]; s.x = fma(Gti[k].x, x, s.x); s.y = fma(Gti[k].y, x, s.y); }
+                V[b] = s;
+            });
             WM_BLOCK {
+                wave_lds_fence();
+                if (r < D) {
 #pragma unroll
-                for (int b = 0; b < D; ++b) {
-                    cplx s = c_make(0.0, 0.0);
-#pragma unroll
-                    for (int k = 0; k < D; ++k) { const double x = kiG[k * D + b]; s.x = fma(Gti[k].x, x, s.x); s.y = fma(Gti[k].y, x, s.y); }
-                    V[b] = s;
+                    for (int k = 0; k < D; ++k) xq[r * D + k] = Gti[k];
                 }
+                wave_lds_fence();
             }
             sfor_bb<0, D>([&](auto bcn) {
                 constexpr int b = decltype(bcn)::value;
                 cplx s = c_make(0.0, 0.0);
 #pragma unroll
-                for (int k = 0; k < D; ++k) s = c_fma(V[k], c_make(bc<b>(Gti[k].x), bc<b>(Gti[k].y)), s);
+                for (int k = 0; k < D; ++k) s = c_fma(V[k], xq[b * D + k], s);
                 Gtl[b] = c_sub(Gtl[b], s);
             });
+            wave_lds_fence();
         }
         if (W.cqq_out && active && r < D) {
             cplx *out = (cplx *)W.cqq_out + tr * (int64_t)DD + r * D;
@@ -416,18 +443,17 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
 
         // ---- M'/(2 pi) = U^T (G0 + CQQ) U / (2 pi) (row i < d') and hat_v = U^T {u_dq, u_n1, w_dQ, w_n1, y} ----
         cplx Mr[DP], hat[5], R[DP];
-        WM_BLOCK {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) R[j] = c_make(0.0, 0.0);
+        sfor_bb<0, D>([&](auto bcn) {
+            constexpr int b = decltype(bcn)::value;
+            const double gre = cG0[r * D + b] + Gtl[b].x;
 #pragma unroll
             for (int j = 0; j < DP; ++j) {
-                cplx s = c_make(0.0, 0.0);
-#pragma unroll
-                for (int b = 0; b < D; ++b) {
-                    const double u = kU[b * DP + j];
-                    s.x = fma(cG0[r * D + b] + Gtl[b].x, u, s.x); s.y = fma(Gtl[b].y, u, s.y);
-                }
-                R[j] = s;
+                const double u = kU[b * DP + j];
+                R[j].x = fma(gre, u, R[j].x); R[j].y = fma(Gtl[b].y, u, R[j].y);
             }
-        }
+        });
 #pragma unroll
         for (int j = 0; j < DP; ++j) Mr[j] = c_make(0.0, 0.0);
 #pragma unroll
