@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        3
+#define SC_ABI_VERSION        4
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -60,10 +60,23 @@ typedef struct sc_potential {
     const double *inv_mass; /* 1/m [D]                                 potentials.py:261-263, 549 */
 } sc_potential;
 
+/* Storage order of the 4 D^2 doubles mono[i] of one trajectory.
+ *   SC_MONO_ROWMAJOR  [4][D][D]: Mqq, Mqp, Mpq, Mpp one after the other, each row-major (a, b).  Every entry point
+ *                     takes this order.
+ *   SC_MONO_TILED16   16 x 16 tiles in the order (ra, rb) of tile rows / columns; tile (ra, rb) stores its nra x ncb
+ *                     part (nra = min(16, D - 16 ra), ncb likewise) of Mqq, Mqp, Mpq, Mpp one after the other, each
+ *                     row-major inside the tile:
+ *                         offset(p, a, b) = 4 (16 ra D + 16 nra rb) + p nra ncb + (a - 16 ra) ncb + (b - 16 rb)
+ *                     Identical to SC_MONO_ROWMAJOR for D <= 16.  Only sc_hk_step on its separable / diagonal-width
+ *                     fast path takes it (the 16 x 16 thread grid of that kernel then walks a trajectory linearly
+ *                     through HBM); sc_mono_convert switches a state between the two in place. */
+#define SC_MONO_ROWMAJOR 0
+#define SC_MONO_TILED16  1
+
 typedef struct sc_state {
     int64_t n;              /* trajectories in this batch (this rank's shard) */
     int32_t dim;            /* D */
-    int32_t _pad;
+    int32_t mono_layout;    /* SC_MONO_ROWMAJOR or SC_MONO_TILED16: storage order inside mono[i], see below */
     double *qp;
     double *act;
     double *mono;
@@ -171,6 +184,10 @@ int sc_tuning_build(void);
  * the caller sizes the `partials` buffers with it. */
 int sc_step_grid(int64_t n, int32_t dim);
 int sc_correlate_grid(int64_t n, int32_t dim);
+
+/* In-place change of st->mono between the storage orders (the caller updates st->mono_layout afterwards);
+ * `to_layout` is the order wanted, st->mono_layout the order the data is in.  D <= 64. */
+int sc_mono_convert(const sc_state *st, int32_t to_layout, void *stream);
 
 /* y (rows = 2D+4D^2+1, n) with n fastest  <->  engine layout.   reference propagators.py:329-334, 581 */
 int sc_state_from_reference(const double *y, const sc_state *st, void *stream);

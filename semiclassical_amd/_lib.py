@@ -19,7 +19,7 @@ class sc_potential(C.Structure):
 
 
 class sc_state(C.Structure):
-    _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("_pad", C.c_int32),
+    _fields_ = [("n", C.c_int64), ("dim", C.c_int32), ("mono_layout", C.c_int32),
                 ("qp", c_double_p), ("act", c_double_p), ("mono", c_double_p),
                 ("c2", c_double_p), ("sgn", c_double_p), ("work", c_double_p), ("flags", C.c_void_p)]
 
@@ -67,10 +67,11 @@ class sc_dense_scratch(C.Structure):
 
 
 SC_POT_MORSE, SC_POT_HARMONIC_SEP, SC_POT_EPS_MORSE, SC_POT_HARMONIC_DENSE = 1, 2, 3, 4
+SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 3              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 4              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 
@@ -82,6 +83,7 @@ SIGNATURES = {
     "sc_last_error": (C.c_char_p, []),
     "sc_step_grid": (C.c_int, [C.c_int64, C.c_int32]),
     "sc_correlate_grid": (C.c_int, [C.c_int64, C.c_int32]),
+    "sc_mono_convert": (C.c_int, [P(sc_state), C.c_int32, C.c_void_p]),
     "sc_state_from_reference": (C.c_int, [c_double_p, P(sc_state), C.c_void_p]),
     "sc_state_to_reference": (C.c_int, [P(sc_state), c_double_p, C.c_void_p]),
     "sc_hk_step": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), C.c_double, C.c_int32,

@@ -122,6 +122,14 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
     }
 }
 
+// offset of element (a, b) of block p inside one trajectory's monodromy storage (include/semiclassical_hip.h)
+__host__ __device__ __forceinline__ int64_t sc_mono_offset(int layout, int D, int p, int a, int b) {
+    if (layout == SC_MONO_ROWMAJOR) return ((int64_t)p * D + a) * D + b;
+    const int ra = a >> 4, rb = b >> 4;
+    const int nra = D - 16 * ra < 16 ? D - 16 * ra : 16, ncb = D - 16 * rb < 16 ? D - 16 * rb : 16;
+    return 4 * ((int64_t)16 * ra * D + 16 * nra * rb) + (int64_t)p * nra * ncb + (a & 15) * ncb + (b & 15);
+}
+
 // ---- shared by the step kernels ----
 struct StepArgs {
     sc_potential pot;
@@ -171,3 +179,4 @@ __device__ __forceinline__ void rk4_pair(double &u, double &v, double im, double
 // host-side error plumbing (sc_api.hip)
 int sc_fail(int code, const char *fmt, ...);
 int sc_check_launch(const char *what);
+int sc_require_rowmajor(const sc_state *st, const char *who);     // sc_layout.hip

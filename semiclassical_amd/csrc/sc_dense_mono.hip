@@ -371,6 +371,7 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
     if (!st || !hk || (mode == 0 && (!inv_mass || !hess)))
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: null argument");
     const int D = st->dim;
+    if (int rq = sc_require_rowmajor(st, "sc_dense_mono_step")) return rq;
     if (D < 1 || D > 96) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d outside 1..96", D);
     if (D > 64 && mode == 0 && !mono_sums)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: D=%d > 64 needs the mono_sums scratch", D);

@@ -282,6 +282,7 @@ extern "C" int sc_energy_guard(const double *energy_partials, int32_t n_blocks, 
 
 extern "C" int sc_state_from_reference(const double *y, const sc_state *st, void *stream) {
     if (!y || !st) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_state_from_reference: null argument");
+    if (int rq = sc_require_rowmajor(st, "sc_state_from_reference")) return rq;
     const int64_t D = st->dim, n = st->n, DD = D * D;
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_transpose(y, st->qp, 2 * D, n, n, 2 * D, s);
@@ -293,6 +294,7 @@ extern "C" int sc_state_from_reference(const double *y, const sc_state *st, void
 
 extern "C" int sc_state_to_reference(const sc_state *st, double *y, void *stream) {
     if (!y || !st) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_state_to_reference: null argument");
+    if (int rq = sc_require_rowmajor(st, "sc_state_to_reference")) return rq;
     const int64_t D = st->dim, n = st->n, DD = D * D;
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_transpose(st->qp, y, n, 2 * D, 2 * D, n, s);

@@ -136,9 +136,15 @@ __global__ __launch_bounds__(256) void hk_step_kernel(StepArgs A) {
 
         // ---------------- phase B: monodromy blocks ----------------
         if (!DENSE) {
+            const int lay = A.st.mono_layout;       // tiled only in the fix-up pass behind the fast path
             for (int e = tid; e < DD; e += nth) {
                 const int a = e / D, b = e - a * D;
-                double mqq = M[e], mqp = M[DD + e], mpq = M[2 * DD + e], mpp = M[3 * DD + e];
+                double mqq, mqp, mpq, mpp;
+                if (lay == SC_MONO_ROWMAJOR) { mqq = M[e]; mqp = M[DD + e]; mpq = M[2 * DD + e]; mpp = M[3 * DD + e]; }
+                else {
+                    mqq = M[sc_mono_offset(lay, D, 0, a, b)]; mqp = M[sc_mono_offset(lay, D, 1, a, b)];
+                    mpq = M[sc_mono_offset(lay, D, 2, a, b)]; mpp = M[sc_mono_offset(lay, D, 3, a, b)];
+                }
                 if (do_step) {
                     const double ima = A.pot.inv_mass[a];
                     const double h1 = hst[a], h2 = hst[D + a], h3 = hst[2 * D + a], h4 = hst[3 * D + a];
@@ -252,6 +258,11 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     if (!dense && pot->kind != SC_POT_MORSE && pot->kind != SC_POT_HARMONIC_SEP && pot->kind != SC_POT_EPS_MORSE)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown potential kind %d", pot->kind);
     bool fast = !dense && hk->diag && st->work;
+    if (st->mono_layout != SC_MONO_ROWMAJOR && st->mono_layout != SC_MONO_TILED16)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown mono_layout %d", st->mono_layout);
+    if (st->mono_layout == SC_MONO_TILED16 && D > 16 && !fast)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: the tiled monodromy layout is only taken on the separable / "
+                       "diagonal-width fast path (sc_mono_convert the state first)");
     int dbg = 0;
 #ifdef SC_TUNING   // experiment knobs exist only in the tuning build (tools/mkvar.sh); the product library reads no environment
     if (getenv("SC_FORCE_GENERAL_STEP")) fast = false;

@@ -136,6 +136,7 @@ template <int NR, int KB>
 __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool live, int kt, int seq, cplx (*rowbuf)[64],
                                                   PivotRecord *pivrec, int *permseq, int *weak) {
     const int tid = threadIdx.x, tj = tid & 15, lane = tid & 63;
+    const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);       // the matrix row (within the block) this thread holds
     // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj)
     const int blk = (__double2hiint(c_abs2(m[KB][KB])) & ~15) | (15 - tj);
     int key_blk = live ? blk : -1;
@@ -152,7 +153,7 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool 
     for (int rb = KB + 1; rb < NR; ++rb) rowbuf[kt][16 * rb + tj] = c_mul(m[KB][rb], inv);
     if (tj == pl) {                                       // the winner publishes the pivot itself
         pivrec[kt].re = m[KB][KB].x; pivrec[kt].im = m[KB][KB].y; pivrec[kt].col = 16 * KB + pl;
-        permseq[16 * KB + kt] = 16 * KB + pl;
+        permseq[16 * KB + trow] = 16 * KB + pl;          // row -> pivot column (the sign of this permutation enters c2)
         __asm__ volatile("" ::: "memory");
         __hip_atomic_store(&pivrec[kt].pad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -175,6 +176,12 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool 
 // with DPP, updates row slot KB first so that the 16 lanes owning row kt+1 can search and publish at once, and only
 // then does the rest of its rank-1 update.  The chain owner(kt) -> owner(kt+1) is the critical path; the bulk of
 // the update floats beside it.  One barrier per block protects the reuse of the 16 row buffers.
+// The pivot ORDER inside a block is kt = 0..15 with thread index ti = 4 j + w (j = 16-lane row of the wave, w = wave):
+// consecutive pivots are owned by different waves.  The matrix ROW a thread holds is trow = 4 w + j (a wave streams
+// four consecutive rows, see the kernel), i.e. pivot step kt eliminates row 4 (kt & 3) + (kt >> 2) of the block; steps
+// whose row lies beyond D are skipped.  The order in which rows are eliminated does not change the determinant.
+__device__ __forceinline__ bool pivot_step_valid(int kt, int nk) { return 4 * (kt & 3) + (kt >> 2) < nk; }
+
 template <int NR, int KB>
 __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bool &singular, int D, int seq,
                                                 cplx (*rowbuf)[64], PivotRecord *pivrec, int *permseq, int *weak) {
@@ -183,7 +190,10 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bo
     bool live = 16 * KB + tj < D;
     __syncthreads();
     if (ti == 0) publish_pivot_row<NR, KB>(m, live, 0, seq, rowbuf, pivrec, permseq, weak);
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < 16; ++kt) {
+        if (!pivot_step_valid(kt, nk)) continue;
+        int next = kt + 1;
+        while (next < 16 && !pivot_step_valid(next, nk)) ++next;
         double re, im;
         int col;
         cplx r[NR];
@@ -205,7 +215,7 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bo
         if (ti <= kt) c[KB] = c_make(0.0, 0.0);
 #pragma unroll
         for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
-        if (kt + 1 < nk && ti == kt + 1) publish_pivot_row<NR, KB>(m, live, kt + 1, seq, rowbuf, pivrec, permseq, weak);
+        if (next < 16 && ti == next) publish_pivot_row<NR, KB>(m, live, next, seq, rowbuf, pivrec, permseq, weak);
 #pragma unroll
         for (int ra = KB + 1; ra < NR; ++ra) {
 #pragma unroll
@@ -214,7 +224,12 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bo
     }
 }
 
-template <int NR, int MINW, bool STEP>
+// TILED: the monodromy blocks of a trajectory are stored as 16 x 16 tiles (sc_state.mono_layout = 1, see the header):
+// tile (ra, rb) holds its part of Mqq, Mqp, Mpq, Mpp one after the other, each row-major inside the tile.  With the
+// row mapping trow = 4 w + j a wave instruction then covers 512 contiguous bytes, the four waves one tile plane, and
+// the workgroup walks the 4 D^2 doubles of the trajectory linearly -- measured 14 % more streaming bandwidth than the
+// 128-byte row segments of the row-major layout (tools/micro/stream_patterns.hip).
+template <int NR, int MINW, bool STEP, bool TILED>
 __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     __shared__ double prop[4 * 64];          // P_a = (p11, p12, p21, p22) of row a
     __shared__ double scl[4 * 64];           // st, 1/st, si, 1/si
@@ -224,9 +239,13 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     __shared__ int weak;
 
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
-    const int ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;   // consecutive rows sit in different waves
+    const int tj = tid & 15;
+    const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);     // wave w holds rows 4w .. 4w+3 of every 16-row slot
     constexpr bool do_step = STEP;                   // false: prefactor and tracker initialisation only (t = 0)
-    const unsigned toff = (unsigned)(ti * D + tj);      // element (ti, tj) of a D x D plane
+    constexpr int NCL_BASE = 16 * (NR - 1);          // first column of the last column tile
+    // per-thread element offsets: row-major (trow, tj) of a D x D plane; tiled: inside a 16-wide / the last tile
+    const unsigned toff = TILED ? (unsigned)(trow * 16 + tj) : (unsigned)(trow * D + tj);
+    const unsigned toffl = (unsigned)(trow * (D - NCL_BASE) + tj);
     if (tid < 64) {
         const bool in = tid < D;
         const double st = in ? A.hk.st[tid] : 1.0, si = in ? A.hk.si[tid] : 1.0;
@@ -256,7 +275,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         // ---------------- phase B ----------------
         // LDS indices derived from til / tjl are recomputed per trajectory: hipcc otherwise hoists them out of the
         // trajectory loop, spills them, and reloads them one by one behind s_waitcnt vmcnt(0) in the middle of the stream
-        int til = ti, tjl = tj;
+        int til = trow, tjl = tj;
         __asm__ volatile("" : "+v"(til), "+v"(tjl));
         cplx m[NR][NR];
 #pragma unroll
@@ -267,27 +286,35 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
             const double p11 = prop[al], p12 = prop[64 + al], p21 = prop[128 + al], p22 = prop[192 + al];
             const double sta = scl[al], ista = scl[64 + al];
             double vqq[NR], vqp[NR], vpq[NR], vpp[NR];
+            // rows / columns of tile (ra, rb); plane = distance between the four blocks of an element
+            const int nra = min(16, D - 16 * ra);
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
                 const bool ok = rowok && 16 * rb + tj < D;
                 // wave-uniform element base (scalar registers) + one per-thread 32-bit offset
-                const double *pe = M + (16 * ra * D + 16 * rb);
-                vqq[rb] = ok ? pe[toff] : 0.0;
-                vqp[rb] = ok ? pe[DD + toff] : 0.0;
-                vpq[rb] = ok ? pe[2 * DD + toff] : 0.0;
-                vpp[rb] = ok ? pe[3 * DD + toff] : 0.0;
+                const int ncb = rb == NR - 1 ? D - NCL_BASE : 16;
+                const double *pe = M + __builtin_amdgcn_readfirstlane(TILED ? 4 * (16 * ra * D + nra * 16 * rb) : 16 * ra * D + 16 * rb);
+                const int plane = __builtin_amdgcn_readfirstlane(TILED ? nra * ncb : DD);
+                const unsigned to = (TILED && rb == NR - 1) ? toffl : toff;
+                vqq[rb] = ok ? pe[to] : 0.0;
+                vqp[rb] = ok ? pe[plane + to] : 0.0;
+                vpq[rb] = ok ? pe[2 * plane + to] : 0.0;
+                vpp[rb] = ok ? pe[3 * plane + to] : 0.0;
             }
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
                 const int b = 16 * rb + tj;
                 const bool ok = rowok && b < D;
-                double *pe = M + (16 * ra * D + 16 * rb);
+                const int ncb = rb == NR - 1 ? D - NCL_BASE : 16;
+                double *pe = M + __builtin_amdgcn_readfirstlane(TILED ? 4 * (16 * ra * D + nra * 16 * rb) : 16 * ra * D + 16 * rb);
+                const int plane = __builtin_amdgcn_readfirstlane(TILED ? nra * ncb : DD);
+                const unsigned to = (TILED && rb == NR - 1) ? toffl : toff;
                 double mqq = vqq[rb], mqp = vqp[rb], mpq = vpq[rb], mpp = vpp[rb];
                 if (do_step) {
                     const double nqq = fma(p12, mpq, p11 * mqq), npq = fma(p22, mpq, p21 * mqq);
                     const double nqp = fma(p12, mpp, p11 * mqp), npp = fma(p22, mpp, p21 * mqp);
                     mqq = nqq; mpq = npq; mqp = nqp; mpp = npp;
-                    if (ok) { pe[toff] = mqq; pe[DD + toff] = mqp; pe[2 * DD + toff] = mpq; pe[3 * DD + toff] = mpp; }
+                    if (ok) { pe[to] = mqq; pe[plane + to] = mqp; pe[2 * plane + to] = mpq; pe[3 * plane + to] = mpp; }
                 }
                 const int bl = (16 * rb + tjl) & 63;
                 const double sib = scl[128 + bl], isib = scl[192 + bl];
@@ -567,10 +594,13 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     }
     if ((a.mode & 0xff) == 0) hipLaunchKernelGGL(hk_modes_kernel, dim3(grid), dim3(256), 0, s, a);
     const bool step = (a.mode & 0xff) == 0;
-#define SC_LAUNCH_SD(NR_, OCC_)                                                                                \
-    do {                                                                                                       \
-        if (step) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true>), dim3(grid), dim3(256), 0, s, a);    \
-        else hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false>), dim3(grid), dim3(256), 0, s, a);        \
+    const bool tiled = a.st.mono_layout == SC_MONO_TILED16;
+#define SC_LAUNCH_SD(NR_, OCC_)                                                                                         \
+    do {                                                                                                                \
+        if (step && tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, true>), dim3(grid), dim3(256), 0, s, a);   \
+        else if (step) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, false>), dim3(grid), dim3(256), 0, s, a);     \
+        else if (tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, true>), dim3(grid), dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, false>), dim3(grid), dim3(256), 0, s, a);              \
     } while (0)
     switch (nr) {
         case 1: SC_LAUNCH_SD(1, 4); break;

@@ -570,6 +570,7 @@ extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const
                                double *partials, void *stream) {
     if (!st || !wc || !zi || !probi || !partials) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: null argument");
     if (wc->dim != st->dim) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: dimension mismatch");
+    if (int rq = sc_require_rowmajor(st, "sc_wm_correlate")) return rq;
     if (wc->dprime < 1 || wc->dprime > st->dim) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: d' outside 1..D");
     if (st->n <= 0) return SC_OK;
     const int D = st->dim, dp = wc->dprime, grid = sc_wm_grid(st->n, D);

@@ -137,8 +137,9 @@ class HermanKlukPropagator(object):
         self._sgn = torch.ones(n, dtype=F64, device=dev)
         self._flags = torch.zeros(n + 1, dtype=torch.int32, device=dev)     # [n] = flagged count
         self._work = torch.zeros((n, 4, d), dtype=F64, device=dev)
-        self._state = sc_state(n=n, dim=d, qp=ptr(self._qp), act=ptr(self._act), mono=ptr(self._mono),
-                               c2=ptr(self._c2), sgn=ptr(self._sgn), work=ptr(self._work), flags=ptr(self._flags))
+        self._state = sc_state(n=n, dim=d, mono_layout=_lib.SC_MONO_ROWMAJOR, qp=ptr(self._qp), act=ptr(self._act),
+                               mono=ptr(self._mono), c2=ptr(self._c2), sgn=ptr(self._sgn), work=ptr(self._work),
+                               flags=ptr(self._flags))
         # ---- per-step scratch ----
         self._gstep = lib.sc_step_grid(n, d)
         self._gcorr = lib.sc_correlate_grid(n, d)
@@ -222,10 +223,12 @@ class HermanKlukPropagator(object):
             e0.record()
         if hasattr(potential, "_gdml_model"):
             self._sync_dense_mono(leave_diagonal=True)
+            self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
             nblocks = self._launch_dense_step(potential, dt, s)
         elif not hasattr(potential, "_descriptor") or self.dim > 64:
             # no device descriptor, or beyond the fused kernels' D <= 64: the potential's own torch code + dense path
             self._sync_dense_mono(leave_diagonal=True)
+            self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
             nblocks = self._launch_generic_step(potential, dt, s)
         else:
             if desc is None:
@@ -235,6 +238,7 @@ class HermanKlukPropagator(object):
                 self._mono_stale = True
             else:
                 self._sync_dense_mono(leave_diagonal=True)
+                self._set_mono_layout(self._fast_path_layout(desc))
                 check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
             nblocks = self._gstep
         if timed:
@@ -250,9 +254,24 @@ class HermanKlukPropagator(object):
         return (self.exploit_separability and self._mono_is_diag and bool(self._pre.diag)
                 and desc.kind in (_lib.SC_POT_MORSE, _lib.SC_POT_HARMONIC_SEP, _lib.SC_POT_EPS_MORSE))
 
+    # The separable fast path streams the monodromy blocks in 16 x 16 tiles (SC_MONO_TILED16, include/semiclassical_hip.h);
+    # everything else reads them row-major.  The state switches order in place when it enters / leaves that path.
+    _tiled_fast_path = True
+
+    def _fast_path_layout(self, desc):
+        fast = (self._tiled_fast_path and bool(self._pre.diag) and 16 < self.dim <= 64
+                and desc.kind in (_lib.SC_POT_MORSE, _lib.SC_POT_HARMONIC_SEP, _lib.SC_POT_EPS_MORSE))
+        return _lib.SC_MONO_TILED16 if fast else _lib.SC_MONO_ROWMAJOR
+
+    def _set_mono_layout(self, layout):
+        if self._state.mono_layout != layout:
+            check(lib.sc_mono_convert(self._state, layout, self._stream()))
+            self._state.mono_layout = layout
+
     def _sync_dense_mono(self, leave_diagonal=False):
         """bring the dense monodromy blocks up to date with the diagonals the shortcut kernel advanced"""
         if self._mono_stale:
+            self._state.mono_layout = _lib.SC_MONO_ROWMAJOR       # rebuilt from the diagonals below
             self._mono.zero_()
             torch.diagonal(self._mono, dim1=2, dim2=3).copy_(self._mdiag)
             self._mono_stale = False
@@ -463,6 +482,7 @@ class HermanKlukPropagator(object):
         d, n = self.dim, self.ntraj
         out = torch.empty((2 * d + 4 * d * d + 1, n), dtype=F64, device=self.device)
         self._sync_dense_mono()
+        self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
         check(lib.sc_state_to_reference(self._state, ptr(out), self._stream()))
         return out
 
@@ -471,6 +491,7 @@ class HermanKlukPropagator(object):
         value = torch.as_tensor(value, dtype=F64).to(self.device).contiguous()
         d, n = self.dim, self.ntraj
         assert value.shape == (2 * d + 4 * d * d + 1, n)
+        self._state.mono_layout = _lib.SC_MONO_ROWMAJOR          # everything in mono is overwritten
         check(lib.sc_state_from_reference(ptr(value), self._state, self._stream()))
         torch.cuda.current_stream(self.device).synchronize()     # `value` may be a temporary
         self._corr_step = -1
@@ -500,6 +521,7 @@ class HermanKlukPropagator(object):
     def monodromy_matrices(self):
         # (n, D, D) -> (D, D, n) views
         self._sync_dense_mono()
+        self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
         return tuple(self._mono[:, k].permute(1, 2, 0) for k in range(4))
 
     def semiclassical_prefactor(self):
@@ -600,6 +622,8 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
     eqns (85) and (100) are evaluated per trajectory by ``sc_wm_correlate`` right after the HK step kernel
     (registers for small matrices, LDS for medium ones, an L2-resident scratch block beyond that: no size limit).
     """
+
+    _tiled_fast_path = False        # the Filinov matrix is built from the row-major blocks after every step
 
     def __init__(self, Gamma_i, Gamma_t, alpha, beta, device='cuda'):
         super().__init__(Gamma_i, Gamma_t, device=device)      # the Filinov matrix needs the dense monodromy blocks

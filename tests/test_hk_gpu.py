@@ -217,10 +217,13 @@ def test_unsupported_sizes_fail_loudly():
     D = 70
     G = torch.diag(torch.linspace(0.5, 1.5, D))
     q0 = torch.zeros(D)
-    # WM keeps every matrix of a trajectory in LDS: D = 70 does not fit
+    # WM without the scratch block its matrices need at this size is refused (the propagator allocates it itself)
     wm = PR.WaltonManolopoulosPropagator(G, G, 10.0, 10.0, device="cuda")
-    with pytest.raises(EngineError, match="LDS"):
-        wm.initial_conditions(q0, q0, G, ntraj=8)
+    wm.initial_conditions(q0, q0, G, ntraj=8)
+    assert wm._wm_scratch is not None and abs(wm.autocorrelation() - 1.0) < 0.5
+    wm._wm.scratch, wm._wm.scratch_bytes = None, 0
+    with pytest.raises(EngineError, match="scratch"):
+        wm._wm_launch(0)
     # the fused step entry point is limited to D <= 64
     st = sc_state(n=1, dim=D)
     with pytest.raises(EngineError, match="outside 1..64"):
@@ -291,3 +294,57 @@ def test_fast_path_at_tile_boundaries(D):
     prop.y = y.cuda()
     prop._prefactor_initial()
     assert cases.rel_err(cnp(prop._c2), ref.c2.numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("D", [17, 33, 50, 60, 64])
+def test_tiled_monodromy_layout_roundtrip_and_parity(D):
+    """SC_MONO_TILED16 (include/semiclassical_hip.h): sc_mono_convert against the documented offset formula, in-place
+    round trip, and the fast path giving the same state in either storage order"""
+    from semiclassical_amd import _lib, potentials as P, propagators as PR
+    from semiclassical_amd._lib import lib, check
+    from oracle import sc_oracle as orc
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(D)
+    n = 37
+    omega = torch.from_numpy(np.sort(rng.uniform(300, 3000, D)) / 219474.63)
+    chi = torch.full((D,), 0.02)
+    nac = torch.from_numpy(rng.normal(0, 1e-4, D))
+    q0 = torch.from_numpy(rng.uniform(-3, 3, D))
+    G = torch.diag(omega)
+
+    def offset(p, a, b):
+        ra, rb = a // 16, b // 16
+        nra, ncb = min(16, D - 16 * ra), min(16, D - 16 * rb)
+        return 4 * (16 * ra * D + 16 * nra * rb) + p * nra * ncb + (a % 16) * ncb + (b % 16)
+    perm = np.array([offset(p, a, b) for p in range(4) for a in range(D) for b in range(D)])
+    assert np.array_equal(np.sort(perm), np.arange(4 * D * D))                 # a bijection
+
+    props = []
+    for tiled in (True, False):
+        prop = PR.HermanKlukPropagator(G, G, device="cuda")
+        prop._tiled_fast_path = tiled
+        prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(5))
+        # dense random monodromy blocks, so that every element position matters
+        y = prop.y
+        y[2 * D:2 * D + 4 * D * D] = torch.from_numpy(rng.uniform(-1, 1, (4 * D * D, n))).cuda() + y[2 * D:2 * D + 4 * D * D]
+        prop.y = y
+        props.append(prop)
+    a, b = props
+    b.y = a.y
+    pot = P.MorsePotential(omega, chi.clone(), nac)
+    for _ in range(3):
+        a.step(pot, 0.3)
+        b.step(pot, 0.3)
+    assert a._state.mono_layout == _lib.SC_MONO_TILED16 and b._state.mono_layout == _lib.SC_MONO_ROWMAJOR
+    raw_tiled = a._mono.reshape(n, -1).clone()
+    assert torch.equal(raw_tiled[:, torch.from_numpy(perm).cuda()], b._mono.reshape(n, -1))     # documented order, same numbers
+    assert torch.equal(a._c2, b._c2) and torch.equal(a._sgn, b._sgn)
+    ya = a.y                                                                  # converts back in place
+    assert a._state.mono_layout == _lib.SC_MONO_ROWMAJOR
+    assert torch.equal(ya, b.y)
+    check(lib.sc_mono_convert(a._state, _lib.SC_MONO_TILED16, None))
+    torch.cuda.synchronize()
+    assert torch.equal(a._mono.reshape(n, -1), raw_tiled)
+    a._state.mono_layout = _lib.SC_MONO_TILED16
+    with pytest.raises(_lib.EngineError, match="tiled monodromy layout"):
+        check(lib.sc_state_to_reference(a._state, _lib.ptr(ya), None))

@@ -37,6 +37,10 @@ def timed(fn, reps=5):
 
 
 desc = prop._potential_descriptor(pot)
+if os.environ.get("LAYOUT", "rowmajor") == "tiled":          # storage order of the monodromy blocks (SC_MONO_TILED16)
+    from semiclassical_amd import _lib
+    prop._set_mono_layout(_lib.SC_MONO_TILED16)
+print("mono_layout", prop._state.mono_layout, "tuning build", lib.sc_tuning_build())
 full = lambda: check(lib.sc_hk_step(desc, prop._state, prop._hk, dt, 0, ptr(prop._epart), prop._stream()))
 pref = lambda: check(lib.sc_hk_step(desc, prop._state, prop._hk, dt, 1, None, prop._stream()))
 ab = bench.algorithmic_bytes_per_traj_step(DIM) * n
