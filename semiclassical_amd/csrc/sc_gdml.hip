@@ -115,22 +115,34 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     __syncthreads();
     // ---- gradient in descriptor space, then Cartesian gradient
     // every wavefront takes a slice of the training points (lanes over the descriptor: coalesced rows), the per-wave
-    // partial sums meet in LDS (L.xsL and L.aL are contiguous and free at this point: 2 * chunk >= nw rows of Dd)
+    // partial sums meet in LDS (L.xsL and L.aL are contiguous and free at this point: 2 * chunk >= 2 * nw rows of Dd)
     for (int d0 = 0; d0 < Dd; d0 += 64) {
         const int d = d0 + lane;
-        double g = 0.0;
         if (d < Dd) {
+            // the terms (2e8) cancel to the size of the force (6e1): Neumaier-compensated accumulation keeps the
+            // rounding of the SUM out of the result (what remains is the rounding of the terms themselves)
             const double xv = L.x[d];
-            for (int m = wave; m < Mt; m += nw)
-                g += L.fm[m] * G.jx_alphas[(size_t)m * Dd + d] - L.ea[m] * (xv - G.xs_train[(size_t)m * Dd + d]);
+            double g = 0.0, comp = 0.0;
+            for (int m = wave; m < Mt; m += nw) {
+                const double t = fma(L.fm[m], G.jx_alphas[(size_t)m * Dd + d], -L.ea[m] * (xv - G.xs_train[(size_t)m * Dd + d]));
+                const double s = g + t;
+                comp += fabs(g) >= fabs(t) ? (g - s) + t : (t - s) + g;
+                g = s;
+            }
             L.xsL[wave * Dd + d] = g;
+            L.xsL[(nw + wave) * Dd + d] = comp;
         }
     }
     __syncthreads();
     for (int d = tid; d < Dd; d += nth) {
-        double g = 0.0;
-        for (int w = 0; w < nw; ++w) g += L.xsL[w * Dd + d];
-        L.gx[d] = g;
+        double g = 0.0, comp = 0.0;
+        for (int w = 0; w < nw; ++w) {
+            const double t = L.xsL[w * Dd + d];
+            const double s = g + t;
+            comp += (fabs(g) >= fabs(t) ? (g - s) + t : (t - s) + g) + L.xsL[(nw + w) * Dd + d];
+            g = s;
+        }
+        L.gx[d] = g + comp;
     }
     __syncthreads();
     for (int xi = tid; xi < X; xi += nth) {
@@ -359,9 +371,9 @@ __global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
 
 // training points per staged chunk: the largest of 16, 8, 4 that fits LDS (measured at 30 atoms: a smaller chunk that
 // lets two workgroups share a CU is slower -- more chunk iterations, each with three barriers); the per-wave partial
-// sums of the descriptor gradient need 2 * chunk >= wavefronts
+// sums (value + compensation term) of the descriptor gradient need chunk >= wavefronts
 int gdml_chunk(const sc_gdml_model *g, int threads) {
-    const int minc = threads / 64 / 2 > 4 ? threads / 64 / 2 : 4;
+    const int minc = threads / 64 > 4 ? threads / 64 : 4;
     for (int c = GDML_CHUNK_MAX; c >= minc; c /= 2)
         if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, c) * 8 <= 160 * 1024) return c;
     return 0;

@@ -1,21 +1,24 @@
-"""`semi dynamics` / `semi rates` on the HIP engine: same JSON task keys and the same ``correlations.npz`` schema.
+"""`semi dynamics` / `semi rates` tasks on the HIP engine.
 
-Mirrors reference semiclassical/cli.py:171-476 (``run_semiclassical_dynamics``) and :519-570
-(``calculate_rates``): potential construction from the task, time grid (including quirk Q3: the stored
-``times`` are ``linspace(0, nt*dt, nt)`` while the propagator advances by ``dt``), batching into repetitions,
-trajectory-weighted running mean in the npz file, ``overwrite`` / accumulate semantics and the ``C(0) = 1``
-assertion.  The time loop itself is ``propagator.run`` (no host synchronisation inside).
+Drop-in for the JSON task lists of the reference (README.rst:90-102; semiclassical/cli.py:171-476
+``run_semiclassical_dynamics``, :519-570 ``calculate_rates``): the same task keys with the same defaults, the same
+``correlations.npz`` keys, the same accumulate / overwrite semantics and the same error texts -- those are the
+contract.  The code around the contract is organised differently from the reference:
+
+    ProblemSetup       what a potential section resolves to (one builder per potential type, registered by name)
+    CorrelationStore   the npz file as a running, trajectory-weighted mean over repetitions and over separate runs
+    propagate_batch    one repetition on the device; the time loop is ``propagator.run`` (no host sync inside)
 
     python -m semiclassical_amd.driver dynamics input.json [--cuda ID]
     python -m semiclassical_amd.driver rates input.json
 
 Not carried over: extxyz export and plotting (outside the hot path).
-Potential types: "harmonic", "anharmonic AS", "gdml" (cli.py:178-303).
 """
 import argparse
 import json
 import logging
 import os
+from collections import namedtuple
 
 import numpy as np
 import torch
@@ -30,146 +33,205 @@ class ConfigurationError(Exception):
     pass
 
 
-def _build_problem(task):
-    """potential, q0, p0, Gamma_0, E_zpt, adiabatic gap from the task's 'potential' section (cli.py:178-303)"""
-    p = task['potential']
-    if p['type'] == "harmonic":
-        with open(p['ground']) as f:
-            freq_fchk = readers.FormattedCheckpointFile(f)
-        with open(p['coupling']) as f:
-            nacs_fchk = readers.FormattedCheckpointFile(f)
-        with open(p['excited']) as f:
-            excited_fchk = readers.FormattedCheckpointFile(f)
-        potential = potentials.MolecularHarmonicPotential(freq_fchk, nacs_fchk)
-        x0, Gamma_0, en_zpt = excited_fchk.vibrational_groundstate()
-        q0 = torch.from_numpy(x0)
-        p0 = torch.zeros_like(q0)
-        Gamma_0 = torch.from_numpy(Gamma_0)
-        potential.minimize(q0)
-        gap = excited_fchk.total_energy() - potential.total_energy()
-        return potential, q0, p0, Gamma_0, en_zpt, gap
-    if p['type'] == "anharmonic AS":
-        data = torch.from_numpy(np.loadtxt(p['model_file']))
-        if len(data.shape) == 1:
-            data = torch.reshape(data, (1, -1))
-        omega = data[:, 0] / units.hartree_to_wavenumbers
-        S, nac, chi = data[:, 1], data[:, 2], data[:, 3]
-        dQ = torch.sqrt(2.0 * abs(S) / omega) * torch.sign(S)
-        dQ[omega == 0.0] = 0.0
-        potential = potentials.MorsePotential(omega, chi, nac)
-        return potential, dQ, 0.0 * dQ, torch.diag(omega), torch.sum(hbar / 2.0 * omega).item(), np.nan
-    if p['type'] == "gdml":
-        from .gdml import MolecularGDMLPotential
-        model_pot = np.load(p['ground'], allow_pickle=True)
-        with open(p['coupling']) as f:
-            nacs_fchk = readers.FormattedCheckpointFile(f)
-        with open(p['excited']) as f:
-            excited_fchk = readers.FormattedCheckpointFile(f)
-        potential = MolecularGDMLPotential(model_pot, nacs_fchk)
-        x0, Gamma_0, en_zpt = excited_fchk.vibrational_groundstate()
-        q0 = torch.from_numpy(x0)
-        p0 = torch.zeros_like(q0)
-        Gamma_0 = torch.from_numpy(Gamma_0)
-        potential.minimize(q0)          # raises the reference's RuntimeError when Newton + Armijo does not converge
-        gap = excited_fchk.total_energy() - potential.total_energy()
-        return potential, q0, p0, Gamma_0, en_zpt, gap
-    raise ConfigurationError(f"Unknown potential type in {task['potential']}")
+# ---------------------------------------------------------------------------------------------------------------------
+# the 'potential' section of a task
+# ---------------------------------------------------------------------------------------------------------------------
+
+ProblemSetup = namedtuple("ProblemSetup", "potential q0 p0 Gamma_0 zero_point_energy adiabatic_gap")
+
+_SETUPS = {}
+
+
+def _potential_type(name):
+    def register(builder):
+        _SETUPS[name] = builder
+        return builder
+    return register
+
+
+def _fchk(path):
+    with open(path) as handle:
+        return readers.FormattedCheckpointFile(handle)
+
+
+def _molecular_setup(surface, excited_state):
+    """Final-state surface + initial wavepacket of a molecule: the wavepacket is the vibrational ground state of the
+    excited-state fchk file; the surface is relaxed from there and its minimum becomes the energy origin, which fixes
+    the adiabatic gap (cli.py:187-197, 293-300)."""
+    centre, widths, zero_point = excited_state.vibrational_groundstate()
+    q0 = torch.from_numpy(centre)
+    surface.minimize(q0)
+    gap = excited_state.total_energy() - surface.total_energy()
+    logger.info(f"  adiabatic excitation energy               : {gap * units.hartree_to_ev:.4f} eV")
+    return ProblemSetup(surface, q0, torch.zeros_like(q0), torch.from_numpy(widths), zero_point, gap)
+
+
+@_potential_type("harmonic")
+def _setup_harmonic(section):
+    surface = potentials.MolecularHarmonicPotential(_fchk(section['ground']), _fchk(section['coupling']))
+    return _molecular_setup(surface, _fchk(section['excited']))
+
+
+@_potential_type("gdml")
+def _setup_gdml(section):
+    from .gdml import MolecularGDMLPotential
+    model = np.load(section['ground'], allow_pickle=True)
+    surface = MolecularGDMLPotential(model, _fchk(section['coupling']))
+    return _molecular_setup(surface, _fchk(section['excited']))     # minimize() may raise, as the reference's does
+
+
+@_potential_type("anharmonic AS")
+def _setup_adiabatic_shift(section):
+    """model file with one row per mode: frequency / cm^-1, Huang-Rhys factor (its sign is the direction of the
+    displacement), coupling, anharmonicity (README.rst:367-373, cli.py:229-285)"""
+    table = torch.from_numpy(np.atleast_2d(np.loadtxt(section['model_file'])))
+    logger.info("vibrational modes (cm^-1):")
+    logger.info(table[:, 0])
+    omega = table[:, 0] / units.hartree_to_wavenumbers
+    huang_rhys, coupling, chi = table[:, 1], table[:, 2], table[:, 3]
+    shift = torch.sign(huang_rhys) * torch.sqrt(2.0 * abs(huang_rhys) / omega)       # S = 1/2 dQ^2 omega
+    shift[omega == 0.0] = 0.0                                                        # zero modes are not displaced
+    zero_point = torch.sum(hbar / 2.0 * omega).item()
+    return ProblemSetup(potentials.MorsePotential(omega, chi, coupling), shift, 0.0 * shift, torch.diag(omega),
+                        zero_point, np.nan)
+
+
+def build_problem(task):
+    section = task['potential']
+    builder = _SETUPS.get(section['type'])
+    if builder is None:
+        raise ConfigurationError(f"Unknown potential type in {task['potential']}")
+    return builder(section)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# correlations.npz
+# ---------------------------------------------------------------------------------------------------------------------
+
+class CorrelationStore(object):
+    """The result file: ``propagator, times, autocorrelation, ic_correlation, adiabatic_gap, zero_point_energy,
+    trajectories`` (cli.py:346-353), re-read and re-written after every batch so that an interrupted run keeps what it
+    has (cli.py:453-476)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def start(self, task, propagator_name, times, setup):
+        fresh = task['results'].get('overwrite', True) is True or not os.path.exists(self.path)
+        if fresh:
+            nt = len(times)
+            np.savez(self.path, propagator=propagator_name, times=times,
+                     autocorrelation=np.zeros((nt,), dtype=complex), ic_correlation=np.zeros((nt,), dtype=complex),
+                     adiabatic_gap=setup.adiabatic_gap, zero_point_energy=setup.zero_point_energy, trajectories=0)
+            return
+        # adding to the results of an earlier run
+        assert task.get('manual_seed', None) is None, \
+            "Multiple runs with the same sequence of random numbers make no sense! Do not use `manual_seed` and `overwrite=False` at the same time"
+        previous = np.load(self.path)
+        assert np.array_equal(previous['times'], times.numpy()), \
+            f"Time steps in {self.path} differ. Delete the old file or change the grid for time propagation."
+        assert previous['propagator'] == propagator_name, "Data produced with different propagators cannot be added."
+
+    def add_batch(self, autocorrelation, ic_correlation, ntraj):
+        """fold the means over ``ntraj`` new trajectories into the stored means"""
+        stored = dict(np.load(self.path))
+        done = stored['trajectories']
+        total = done + ntraj
+        stored['autocorrelation'] = (ntraj * autocorrelation + done * stored['autocorrelation']) / total
+        stored['ic_correlation'] = (ntraj * ic_correlation + done * stored['ic_correlation']) / total
+        stored['trajectories'] = total
+        stored.pop('ic_rate', None)          # a rate computed from the old correlation function is stale now
+        logger.info(f"<phi(0)|phi(0)>= {stored['autocorrelation'][0]}")
+        assert abs(stored['autocorrelation'][0] - 1.0) < 1.0e-3
+        np.savez(self.path, **stored)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dynamics
+# ---------------------------------------------------------------------------------------------------------------------
+
+def make_propagator(task, Gamma_0, device):
+    """frozen Gaussians of the width of the initial wavepacket: Gamma_i = Gamma_t = Gamma_0 (cli.py:305-306, 376-383)"""
+    if task.get('propagator', 'HK') == "WM":
+        cell = task.get('cell_width', 10000.0)
+        return propagators.WaltonManolopoulosPropagator(Gamma_0, Gamma_0, cell, cell, device=device)
+    return propagators.HermanKlukPropagator(Gamma_0, Gamma_0, device=device)
+
+
+def propagate_batch(propagator, setup, dt, nt, times, norm_every=0):
+    """C_auto(t), k_ic(t) of one batch of trajectories.  ``norm_every`` > 0 logs the wavefunction norm (the O(n^2)
+    convergence diagnostic of cli.py:424-429) at every norm_every-th step by cutting the device loop there."""
+    if norm_every <= 0:
+        return propagator.run(setup.potential, dt, nt, energy0_es=setup.zero_point_energy)
+    pieces = []
+    for first in range(0, nt, norm_every):
+        logger.info(f" time/fs= {times[first] * units.autime_to_fs}  norm= {propagator.norm():9.6f}")
+        pieces.append(propagator.run(setup.potential, dt, min(norm_every, nt - first),
+                                     energy0_es=setup.zero_point_energy))
+    return tuple(np.concatenate(part) for part in zip(*pieces))
 
 
 def run_semiclassical_dynamics(task, device='cuda'):
     torch.set_default_dtype(torch.float64)
-    potential, q0, p0, Gamma_0, en_zpt, adiabatic_gap = _build_problem(task)
-    Gamma_i = Gamma_t = Gamma_0
+    setup = build_problem(task)
 
     dt = task['time_step_fs'] / units.autime_to_fs
     nt = task['num_steps']
-    times = torch.linspace(0.0, nt * dt, nt)                                  # quirk Q3, cli.py:312-313
+    # SURVEY quirk Q3: the stored grid has spacing nt dt / (nt - 1) while the propagator advances by dt (cli.py:312-313)
+    times = torch.linspace(0.0, nt * dt, nt)
 
     batch_size = task.get('batch_size', 10000)
     num_trajectories = task.get('num_trajectories', 50000)
-    num_repetitions = max(num_trajectories // batch_size, 1)
-    num_samples = min(batch_size, num_trajectories)
-    propagator_name = task.get('propagator', 'HK')
+    repetitions = max(num_trajectories // batch_size, 1)
+    per_batch = min(batch_size, num_trajectories)
 
-    filename = task['results'].get('correlations', 'correlations.npz')
-    if task['results'].get('overwrite', True) is True or (not os.path.exists(filename)):
-        np.savez(filename, propagator=propagator_name, times=times,
-                 autocorrelation=np.zeros((nt,), dtype=complex), ic_correlation=np.zeros((nt,), dtype=complex),
-                 adiabatic_gap=adiabatic_gap, zero_point_energy=en_zpt, trajectories=0)
-    else:
-        assert task.get('manual_seed', None) is None, \
-            "Multiple runs with the same sequence of random numbers make no sense! Do not use `manual_seed` and `overwrite=False` at the same time"
-        data = np.load(filename)
-        assert np.array_equal(data['times'], times.numpy()), \
-            f"Time steps in {filename} differ. Delete the old file or change the grid for time propagation."
-        assert data['propagator'] == propagator_name, "Data produced with different propagators cannot be added."
+    store = CorrelationStore(task['results'].get('correlations', 'correlations.npz'))
+    store.start(task, task.get('propagator', 'HK'), times, setup)
 
     seed = task.get('manual_seed', None)
     if seed is not None:
         logger.warning("The random number generator should not be seeded manually unless for debugging!")
         torch.manual_seed(seed)
 
-    for repetition in range(num_repetitions):
+    for repetition in range(repetitions):
         logger.info(f"*** Repetition {repetition + 1} ***")
-        if propagator_name == "WM":
-            alpha = task.get('cell_width', 10000.0)
-            propagator = propagators.WaltonManolopoulosPropagator(Gamma_i, Gamma_t, alpha, alpha, device=device)
-        else:
-            propagator = propagators.HermanKlukPropagator(Gamma_i, Gamma_t, device=device)
-        propagator.initial_conditions(q0, p0, Gamma_0, ntraj=num_samples)
-        calc_norm_every = task.get('calc_norm_every', 0)
-        if calc_norm_every > 0:
-            # convergence diagnostic of cli.py:424-429 (O(ntraj^2)): the fused loop is cut at the steps where the
-            # norm is wanted
-            parts = []
-            for t0 in range(0, nt, calc_norm_every):
-                logger.info(f" time/fs= {times[t0] * units.autime_to_fs}  norm= {propagator.norm():9.6f}")
-                parts.append(propagator.run(potential, dt, min(calc_norm_every, nt - t0), energy0_es=en_zpt))
-            autocorrelation_ = np.concatenate([c for c, _ in parts])
-            ic_correlation_ = np.concatenate([k for _, k in parts])
-        else:
-            autocorrelation_, ic_correlation_ = propagator.run(potential, dt, nt, energy0_es=en_zpt)
-        assert not np.isnan(autocorrelation_).any(), f"encountered NaN's in autocorrelation : {autocorrelation_}"
-        assert not np.isnan(ic_correlation_).any(), f"encountered NaN's in IC correlation : {ic_correlation_}"
+        propagator = make_propagator(task, setup.Gamma_0, device)
+        propagator.initial_conditions(setup.q0, setup.p0, setup.Gamma_0, ntraj=per_batch)
+        autocorrelation, ic_correlation = propagate_batch(propagator, setup, dt, nt, times,
+                                                          norm_every=task.get('calc_norm_every', 0))
+        assert not np.isnan(autocorrelation).any(), f"encountered NaN's in autocorrelation : {autocorrelation}"
+        assert not np.isnan(ic_correlation).any(), f"encountered NaN's in IC correlation : {ic_correlation}"
+        store.add_batch(autocorrelation, ic_correlation, per_batch)
 
-        data = dict(np.load(filename))
-        ntraj_old, ntraj_new = data['trajectories'], num_samples
-        ntraj_tot = ntraj_old + ntraj_new
-        autocorrelation = (ntraj_new * autocorrelation_ + ntraj_old * data['autocorrelation']) / ntraj_tot
-        ic_correlation = (ntraj_new * ic_correlation_ + ntraj_old * data['ic_correlation']) / ntraj_tot
-        logger.info(f"<phi(0)|phi(0)>= {autocorrelation[0]}")
-        assert abs(autocorrelation[0] - 1.0) < 1.0e-3
-        data['trajectories'] = ntraj_tot
-        data['autocorrelation'] = autocorrelation
-        data['ic_correlation'] = ic_correlation
-        data.pop('ic_rate', None)
-        np.savez(filename, **data)
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rates
+# ---------------------------------------------------------------------------------------------------------------------
+
+def lineshape_from_task(task):
+    """damping function of the 'broadening' keys; widths are half widths at half maximum in eV (cli.py:524-545)"""
+    kind = task.get('broadening', 'gaussian')
+    hwhm_gauss, hwhm_lorentz = task.get('hwhmG_ev', 0.01), task.get('hwhmL_ev', 1.0e-6)
+    sigma = hwhm_gauss / np.sqrt(2.0 * np.log(2.0)) / units.hartree_to_ev
+    gamma = hwhm_lorentz / units.hartree_to_ev
+    shapes = {"gaussian": lambda: broadening.gaussian(sigma),
+              "lorentzian": lambda: broadening.lorentzian(gamma),
+              "voigtian": lambda: broadening.voigtian(sigma, gamma)}
+    if kind not in shapes:
+        raise ValueError("'broadening' should be one of 'gaussian', 'lorentzian' or 'voigtian'")
+    return shapes[kind](), {'broadening': kind, 'hwhmG': hwhm_gauss, 'hwhmL': hwhm_lorentz}
 
 
 def calculate_rates(task):
-    """Fourier transform of k_ic(t) into k_ic(E), cli.py:519-570 (including the factor 2 pi of :564)"""
-    hwhmG = task.get('hwhmG_ev', 0.01)
-    hwhmL = task.get('hwhmL_ev', 1.0e-6)
-    sigma = hwhmG / np.sqrt(2.0 * np.log(2.0)) / units.hartree_to_ev
-    gamma = hwhmL / units.hartree_to_ev
-    broad = task.get('broadening', 'gaussian')
-    if broad == "gaussian":
-        lineshape = broadening.gaussian(sigma)
-    elif broad == "lorentzian":
-        lineshape = broadening.lorentzian(gamma)
-    elif broad == "voigtian":
-        lineshape = broadening.voigtian(sigma, gamma)
-    else:
-        raise ValueError("'broadening' should be one of 'gaussian', 'lorentzian' or 'voigtian'")
-    corr_file = task.get('correlations', 'correlations.npz')
-    rate_file = task.get('rates', 'correlations.npz')
-    data = dict(np.load(corr_file))
-    data['broadening'], data['hwhmG'], data['hwhmL'] = broad, hwhmG, hwhmL
-    energies, ic_rate = rates.rate_from_correlation(data['times'], data['ic_correlation'], lineshape)
-    ic_rate *= 2.0 * np.pi
-    data['energies'] = energies[energies >= 0.0]
-    data['ic_rate'] = ic_rate[energies >= 0.0].real
-    np.savez(rate_file, **data)
+    """k_ic(E) from the stored k_ic(t): damped Fourier transform, factor 2 pi, non-negative energies (cli.py:547-570)"""
+    lineshape, record = lineshape_from_task(task)
+    stored = dict(np.load(task.get('correlations', 'correlations.npz')))
+    stored.update(record)
+    energies, spectrum = rates.rate_from_correlation(stored['times'], stored['ic_correlation'], lineshape)
+    keep = energies >= 0.0
+    stored['energies'] = energies[keep]
+    stored['ic_rate'] = (2.0 * np.pi * spectrum)[keep].real
+    np.savez(task.get('rates', 'correlations.npz'), **stored)
 
 
 def main(argv=None):
@@ -184,11 +246,11 @@ def main(argv=None):
     args = parser.parse_args(argv)
     with open(args.json_input) as f:
         config = json.load(f)
+    handlers = {'dynamics': lambda task: run_semiclassical_dynamics(task, device=f"cuda:{args.cuda}"),
+                'rates': calculate_rates}
     for task in config['semi']:
-        if args.command == 'dynamics' and task['task'] == 'dynamics':
-            run_semiclassical_dynamics(task, device=f"cuda:{args.cuda}")
-        elif args.command == 'rates' and task['task'] == 'rates':
-            calculate_rates(task)
+        if task['task'] == args.command:
+            handlers[args.command](task)
 
 
 if __name__ == "__main__":

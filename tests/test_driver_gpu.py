@@ -62,3 +62,85 @@ def test_calc_norm_every_does_not_change_the_correlations(tmp_path, caplog):
     assert np.allclose(res[0]["autocorrelation"], res[1]["autocorrelation"], rtol=1e-13, atol=0)
     assert np.allclose(res[0]["ic_correlation"], res[1]["ic_correlation"], rtol=1e-13, atol=0)
     assert sum("norm=" in r.getMessage() for r in caplog.records) == 3          # t = 0, 7, 14
+
+
+FCHK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fchk")
+
+
+def _inject_initial_conditions(monkeypatch, zis, probis):
+    """the reference's sampled phase-space points, repetition by repetition (parity is pinned on zi / probi, never on
+    the seed: SURVEY.md section 8c)"""
+    from semiclassical_amd import propagators as PR
+    count = {"rep": 0}
+
+    def from_golden(self, q0, p0, Gamma_0, ntraj=5000, **kwargs):
+        rep = count["rep"]
+        count["rep"] += 1
+        assert zis[rep].shape[1] == ntraj
+        self.set_initial_conditions(q0, p0, Gamma_0, cases.T(zis[rep]), cases.T(probis[rep]))
+    monkeypatch.setattr(PR.HermanKlukPropagator, "initial_conditions", from_golden)
+    return count
+
+
+@pytest.mark.parametrize("prop,tol", [("HK", 1e-8), ("WM", 1e-7)])
+def test_harmonic_task_matches_reference_driver(prop, tol, tmp_path, monkeypatch):
+    """Row N3: the reference's own example task (tests/DATA/examples/methylium_AH/semi.json: harmonic potential from
+    three fchk files, then the rates task) through semiclassical_amd.driver, against the npz the REFERENCE's
+    run_semiclassical_dynamics + calculate_rates wrote for the same sampled initial conditions
+    (tests/golden/driver_methylium.npz, cli.py:171-476, 519-570)."""
+    from semiclassical_amd import driver
+    g = cases.load("driver_methylium")
+    task = json.loads(str(g[f"{prop}_task"]))
+    out = tmp_path / "correlations.npz"
+    task["potential"] = {"type": "harmonic", "ground": os.path.join(FCHK, "methylium_s0.fchk"),
+                         "excited": os.path.join(FCHK, "methylium_s1.fchk"),
+                         "coupling": os.path.join(FCHK, "methylium_s1.fchk")}
+    task["results"] = {"correlations": str(out)}
+    count = _inject_initial_conditions(monkeypatch, g[f"{prop}_zi"], g[f"{prop}_probi"])
+    driver.run_semiclassical_dynamics(task, device="cuda")
+    assert count["rep"] == 2                                         # 96 trajectories in batches of 48
+    driver.calculate_rates(dict(json.loads(str(g["rates_task"])), correlations=str(out), rates=str(out)))
+    got = dict(np.load(out))
+    ref = {k[len(prop) + 1:]: v for k, v in g.items() if k.startswith(prop + "_") and k[len(prop) + 1:] not in ("zi", "probi", "task")}
+    assert set(got) == set(ref), set(got) ^ set(ref)                 # the same npz keys
+    assert str(got["propagator"]) == prop and int(got["trajectories"]) == int(ref["trajectories"]) == 96
+    assert np.array_equal(got["times"], ref["times"])
+    assert abs(float(got["zero_point_energy"]) - float(ref["zero_point_energy"])) < 1e-12
+    assert abs(float(got["adiabatic_gap"]) - float(ref["adiabatic_gap"])) < 1e-10
+    assert cases.rel_err(got["autocorrelation"], ref["autocorrelation"]) < tol
+    assert cases.rel_err(got["ic_correlation"], ref["ic_correlation"]) < tol
+    assert np.array_equal(got["energies"], ref["energies"])
+    assert cases.rel_err(got["ic_rate"], ref["ic_rate"]) < 10 * tol
+    assert str(got["broadening"]) == str(ref["broadening"]) and float(got["hwhmG"]) == float(ref["hwhmG"])
+
+
+def test_gdml_task_runs_through_the_driver(tmp_path):
+    """'gdml' potential type (cli.py:204-227) on the coumarin model.  The reference itself does not get through this
+    task: its Newton / Armijo minimisation from the S1 geometry solves with a Hessian that has six zero modes and
+    gives up ("Could not find minimum within 200 iterations.", tests/golden/driver_gdml.npz).  Which way such an
+    iteration goes depends on the last bits of the Hessian, so the driver -- same algorithm on the GPU-evaluated
+    surface -- may end the same way or converge; both are accepted, anything else is not."""
+    from semiclassical_amd import driver
+    g = cases.load("driver_gdml")
+    task = json.loads(str(g["task"]))
+    out = tmp_path / "c.npz"
+    task["potential"] = {"type": "gdml", "ground": os.path.join(cases.GOLDEN, "gdml_coumarin_model.npz"),
+                         "excited": os.path.join(FCHK, "coumarin_s1.fchk"),
+                         "coupling": os.path.join(FCHK, "coumarin_s1.fchk")}
+    task["results"] = {"correlations": str(out)}
+    assert str(g["outcome"]) == "RuntimeError"
+    try:
+        driver.run_semiclassical_dynamics(task, device="cuda")
+    except RuntimeError as err:
+        assert str(err) == str(g["message"])
+        return
+    d = np.load(out)
+    assert int(d["trajectories"]) == 8 and str(d["propagator"]) == "HK"
+    assert abs(d["autocorrelation"][0] - 1.0) < 1e-3 and np.isfinite(d["ic_correlation"]).all()
+    assert np.isfinite(float(d["adiabatic_gap"])) and float(d["zero_point_energy"]) > 0.0
+
+
+def test_unknown_potential_type():
+    from semiclassical_amd import driver
+    with pytest.raises(driver.ConfigurationError, match="Unknown potential type"):
+        driver.build_problem({"potential": {"type": "quartic"}})

@@ -13,18 +13,36 @@ def cnp(t):
     return t.detach().cpu().numpy()
 
 
+# Achieved deviations on MI355X (tools/gdml_parity.py, profiles/r2_gdml_parity.txt), max-norm relative:
+#                      E         grad      hess
+#   HIP vs reference   3.7e-12   1.5e-08   2.4e-09
+#   HIP vs truth       6.4e-13   1.3e-08   1.1e-09      truth = the same formulas in x87 extended precision
+#   reference vs truth 2.7e-12   1.2e-08   1.6e-09      (oracle/gdml_truth.py, tests/golden/gdml_coumarin_truth.npz)
+# The sums cancel terms of 2e8 down to 6e1: the REFERENCE's fp64 gradient is itself 1.2e-8 away from the exact value,
+# so no fp64 implementation can agree with it to better than ~1e-8 -- the kernel (compensated accumulation of the
+# descriptor-space gradient) is as close to the truth as the reference is.  Asserted: 3 x the achieved figures.
+TOL_E, TOL_GRAD, TOL_HESS = 1e-11, 5e-8, 1e-8
+TOL_GRAD_TRUTH, TOL_HESS_TRUTH = 4e-8, 4e-9
+# propagation on the coumarin surface (8 steps): achieved c2 1.3e-10, y 7.6e-11, C(t) 1.4e-09, k_ic(t) 1.0e-09
+TOL_C2, TOL_Y, TOL_CORR = 1e-8, 1e-9, 1e-8
+
+
 def test_gdml_energy_gradient_hessian_match_reference():
     from tests.engine_cases import engine_potential
-    g = cases.load("gdml_coumarin_eval")
+    g, truth = cases.load("gdml_coumarin_eval"), cases.load("gdml_coumarin_truth")
     pot = engine_potential(dict(potential="gdml", nac0=np.zeros(51), masses=np.ones(51), origin=0.0))
     r = torch.from_numpy(g["r"]).t().contiguous().cuda()                 # (D, n)
     v, grad, hess = pot.harmonic_approximation(r)
-    assert cases.rel_err(cnp(v), g["energy"]) < 1e-11      # E = std*sum + c cancels 1e4 Hartree
-    # the sGDML sums cancel terms of 2e8 down to 6e1: re-ordering the training points in the reference's own
-    # formula already moves grad by 2e-8 and hess by 2e-9 (tests/test_oracle.py::test_gdml_sum_conditioning)
-    assert cases.rel_err(cnp(grad.t()), g["grad"]) < 2e-7
-    assert cases.rel_err(cnp(hess.permute(2, 0, 1)), g["hess"]) < 2e-7
-    h = cnp(hess.permute(2, 0, 1))
+    v, grad, h = cnp(v), cnp(grad.t()), cnp(hess.permute(2, 0, 1))
+    dev = (cases.rel_err(v, g["energy"]), cases.rel_err(grad, g["grad"]), cases.rel_err(h, g["hess"]))
+    dev_truth = (cases.rel_err(v[:3], truth["energy"]), cases.rel_err(grad[:3], truth["grad"]), cases.rel_err(h[:3], truth["hess"]))
+    print(f"sGDML E/grad/hess: HIP vs reference {dev[0]:.2e} {dev[1]:.2e} {dev[2]:.2e} | HIP vs extended precision "
+          f"{dev_truth[0]:.2e} {dev_truth[1]:.2e} {dev_truth[2]:.2e} | reference vs extended precision "
+          f"{truth['ref_dev'][0]:.2e} {truth['ref_dev'][1]:.2e} {truth['ref_dev'][2]:.2e}")
+    assert dev[0] < TOL_E and dev[1] < TOL_GRAD and dev[2] < TOL_HESS
+    assert dev_truth[0] < TOL_E and dev_truth[1] < TOL_GRAD_TRUTH and dev_truth[2] < TOL_HESS_TRUTH
+    # not further from the exact value than twice the reference's own fp64 rounding
+    assert dev_truth[1] < 2.0 * truth["ref_dev"][1] and dev_truth[2] < 2.0 * truth["ref_dev"][2]
     assert np.max(np.abs(h - h.transpose(0, 2, 1))) < 1e-10 * np.max(np.abs(h))   # reference tests/test_gdml_predictor.py:90-122
 
 
@@ -36,8 +54,9 @@ def test_hk_on_gdml_surface_matches_reference_golden():
     nt, dt, E0 = int(g["nt"]), float(g["dt"]), float(g["E0"])
     cauto = np.zeros(nt, dtype=complex)
     kic = np.zeros(nt, dtype=complex)
+    dc2 = dy = 0.0
     for t in range(nt):
-        assert cases.rel_err(cnp(prop._c2), g["c2"][t]) < 1e-6, f"c2 at step {t}"
+        dc2 = max(dc2, cases.rel_err(cnp(prop._c2), g["c2"][t]))
         cauto[t] = prop.autocorrelation(E0)
         kic[t] = prop.ic_correlation(pot, E0)
         prop.step(pot, dt)
@@ -45,12 +64,13 @@ def test_hk_on_gdml_surface_matches_reference_golden():
         if step in g["snaps"]:
             y = cnp(prop.y)
             d = prop.dim
-            assert cases.rel_err(np.vstack((y[:2 * d], y[-1:])), g[f"qpS_{step}"]) < 1e-7
-            assert cases.rel_err(y[:, 0], g[f"ytraj0_{step}"]) < 1e-7
+            dy = max(dy, cases.rel_err(np.vstack((y[:2 * d], y[-1:])), g[f"qpS_{step}"]), cases.rel_err(y[:, 0], g[f"ytraj0_{step}"]))
             assert np.array_equal(cnp(prop._sgn), g[f"signs_{step}"].real)
     prop.synchronize()
-    assert cases.rel_err(cauto, g["cauto"]) < 1e-6        # north_star tolerance (force conditioning, see above)
-    assert cases.rel_err(kic, g["kic"]) < 1e-6
+    dc, dk = cases.rel_err(cauto, g["cauto"]), cases.rel_err(kic, g["kic"])
+    print(f"HK on the coumarin sGDML surface: c2 {dc2:.2e}  y {dy:.2e}  C(t) {dc:.2e}  k_ic(t) {dk:.2e}")
+    assert dc2 < TOL_C2 and dy < TOL_Y
+    assert dc < TOL_CORR and dk < TOL_CORR                 # north_star asks 1e-6
 
 
 def synthetic_model(n_atoms, n_train, seed):
@@ -69,6 +89,9 @@ def synthetic_model(n_atoms, n_train, seed):
              "R_desc": R_desc, "R_d_desc_alpha": alpha, "perms": np.arange(n_atoms)[None, :],
              "tril_perms_lin": np.arange(len(k))}
     return model, pos
+
+
+TOL30 = (1e-10, 1e-7, 1e-7, 1e-6, 1e-6)       # E, grad, hess, y, c2 (tightened below the achieved figures x 3 once measured)
 
 
 def test_gdml_30_atoms_matches_oracle():
@@ -101,9 +124,10 @@ def test_gdml_30_atoms_matches_oracle():
     r = torch.from_numpy(pos.reshape(1, -1) + rng.normal(0, 0.05, (6, 3 * N)))            # (B, 3N)
     e_ref, g_ref, h_ref = ref.forward(r)
     v, grad, hess = pot.harmonic_approximation(r.t().contiguous().cuda())
-    assert cases.rel_err(cnp(v), e_ref.numpy()) < 1e-10
-    assert cases.rel_err(cnp(grad.t()), g_ref.numpy()) < 1e-7
-    assert cases.rel_err(cnp(hess.permute(2, 0, 1)), h_ref.numpy()) < 1e-7
+    dev = (cases.rel_err(cnp(v), e_ref.numpy()), cases.rel_err(cnp(grad.t()), g_ref.numpy()),
+           cases.rel_err(cnp(hess.permute(2, 0, 1)), h_ref.numpy()))
+    print(f"30-atom synthetic sGDML model, HIP vs oracle: E {dev[0]:.2e}  grad {dev[1]:.2e}  hess {dev[2]:.2e}")
+    assert dev[0] < TOL30[0] and dev[1] < TOL30[1] and dev[2] < TOL30[2]
     # two HK steps at D = 90 against the oracle propagator on the same surface
     opot = orc.MolecularGDMLOracle(model, masses, nac0, origin=0.0)
     q0 = torch.from_numpy(pos.reshape(-1))
@@ -116,5 +140,6 @@ def test_gdml_30_atoms_matches_oracle():
     for _ in range(2):
         oprop.step(opot, 5.0)
         prop.step(pot, 5.0)
-    assert cases.rel_err(cnp(prop.y), oprop.y.numpy()) < 1e-6
-    assert cases.rel_err(cnp(prop._c2), oprop.c2.numpy()) < 1e-6
+    dy, dc2 = cases.rel_err(cnp(prop.y), oprop.y.numpy()), cases.rel_err(cnp(prop._c2), oprop.c2.numpy())
+    print(f"two HK steps at D = 90: y {dy:.2e}  c2 {dc2:.2e}")
+    assert dy < TOL30[3] and dc2 < TOL30[4]
