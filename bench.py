@@ -1,13 +1,21 @@
 #!/usr/bin/env python
 """Headline benchmark: trajectory-steps/s of the HK loop on the synthetic 60-mode anharmonic-AS model.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--ntraj n_per_gpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--ntraj n_per_gpu | --ntraj-total n]
 
 A "step" is one pass of the hot path over one batch: (C_auto, k_ic, RK4 step + prefactor) for all
 trajectories (the loop body of reference cli.py:401-436).  Workload = BASELINE.json configs[1]:
 anharmonic-AS, D = 60, 10^5 trajectories per GPU, HK, fp64, dt = 0.005 fs.
 Inputs are resident in HBM before the timed region; the timed region ends with the single all-reduce
 of the accumulated correlation sums (the "flush").  One JSON line is printed by rank 0.
+
+--gpus N without WORLD_SIZE in the environment: this process only starts N rank processes (one per GPU, RCCL
+process group) and waits; it never touches the GPU itself.  At --gpus 8 the default size is BASELINE configs[3]:
+10^6 trajectories in total = 8 x 125 000.
+
+At N = 1 the line also carries: `configs` (the other single-GPU BASELINE configurations with their dominant kernels'
+durations and roofline fractions), `wall_to_full_Ct_s` (a real 2000-step run of the headline configuration),
+`separable_shortcut` (the opt-in structure-exploiting path, reported apart) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -20,23 +28,16 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-HBM_PEAK_GBS = 8000.0   # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet, vector = matrix FP64 (the guide gives no FP64 figure)
 
 
 def as60_model(dim=60):
     """synthetic 60-mode AS model, SURVEY.md section 8d config 2 (other `dim` only for the tools/ experiments)"""
-    from semiclassical_amd import units
-    rng = np.random.default_rng(60)
-    omega_cm = np.linspace(160.0, 3300.0, dim)
-    S = rng.uniform(0, 0.1, dim) * rng.choice([-1, 1], dim)
-    nac = rng.normal(0, 1e-4, dim)
-    chi = np.full(dim, 0.02)
-    omega = torch.from_numpy(omega_cm / units.hartree_to_wavenumbers)
-    S, nac, chi = torch.from_numpy(S), torch.from_numpy(nac), torch.from_numpy(chi)
-    q0 = torch.sqrt(2.0 * abs(S) / omega) * torch.sign(S)
-    dt = 0.005 / units.autime_to_fs
-    return omega, chi, nac, q0, dt
+    from semiclassical_amd.synthetic import anharmonic_as_model
+    return anharmonic_as_model(dim)
 
 
 def algorithmic_bytes_per_traj_step(D):
@@ -44,16 +45,30 @@ def algorithmic_bytes_per_traj_step(D):
     return 64 * D * D + 64 * D + 72
 
 
+def wm_flops_per_traj_step(D, dp):
+    """real flops (2 per multiply-add) of the Walton-Manolopoulos prefactor + correlation terms as the engine computes
+    them (csrc/sc_wm_small.hip header): Mq', Mp', Gt Mq', the two e x e Gram matrices, the
+    e x e complex elimination with D right-hand sides, eqns (57), (59), (70), the projected M', its elimination"""
+    E = 2 * dp
+    fma = (2 * D * D * E + D * D * E + 2 * E * E * D            # Mq', Mp' ; Tq ; G, S
+           + 4 * E * E * (E // 2 + D)                           # Gauss-Jordan on A' with D right-hand sides (complex)
+           + 4 * D * D * E + 2 * D * D * E                      # (57), (59)
+           + 2 * D ** 3 + 4 * D ** 3                            # V, CQQ (70)
+           + 2 * D * D * dp + 2 * dp * dp * D + 10 * D * dp     # M', hat vectors
+           + 4 * dp * dp * (dp // 2 + 5))                       # Gauss-Jordan on M' with 5 right-hand sides
+    return 2 * fma
+
+
 def profiled_traffic(n, dim):
     """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/), if they match this workload"""
-    path = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        if t["workload"]["ntraj"] == n and t["workload"]["dim"] == dim:
-            return t["traffic_bytes_per_launch"], "profiles/r1_hbm_traffic.json (FETCH_SIZE calibrated + WRITE_SIZE, separate passes)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r2_hbm_traffic.json", "r1_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if t["workload"]["ntraj"] == n and t["workload"]["dim"] == dim:
+                return t["traffic_bytes_per_launch"], f"profiles/{name} (FETCH_SIZE calibrated + WRITE_SIZE, separate passes)"
+        except (OSError, KeyError, ValueError):
+            continue
     return None, None
 
 
@@ -108,6 +123,159 @@ def separable_shortcut(pot, omega, q0, dt, E0, n, K, W, dev):
                     "diagonal prefactor; NOT the dense-state kernel the roofline object describes"}
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# the other single-GPU configurations of BASELINE.json (driver-timed, N = 1 only)
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def _T(x):
+    return torch.from_numpy(np.asarray(x)).clone()
+
+
+def _timed_loop(prop, pot, dt, E0, steps, dev, use_graph=False, reps=3):
+    """median wall time of `reps` fused loops of `steps` steps (after one warm-up loop); seconds"""
+    slots = torch.zeros((steps, 5), dtype=torch.float64, device=dev)
+    prop.run(pot, dt, min(steps, 3), E0, slots=slots, use_graph=False)
+    torch.cuda.synchronize(dev)
+    walls = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        prop.run(pot, dt, steps, E0, slots=slots, use_graph=use_graph)
+        torch.cuda.synchronize(dev)
+        walls.append(time.perf_counter() - t0)
+    prop.synchronize()
+    return float(np.median(walls))
+
+
+def _kernel_ms(prop, pot, dt, E0, steps, dev):
+    """mean duration per launch of every labelled kernel over one more loop (HIP events on the launch stream)"""
+    prop.__dict__.pop("_kernel_events", None)
+    prop.kernel_timing = True
+    prop.run(pot, dt, steps, E0, slots=torch.zeros((steps, 5), dtype=torch.float64, device=dev))
+    prop.kernel_timing = False
+    return {k: float(np.mean(v)) for k, v in prop.kernel_times_ms().items()}
+
+
+def config1(dev, n, steps):
+    """configs[0]: 5-mode anharmonic AS (the reference's tests/DATA/AnharmonicAS/5modes model, chi = 0.02), HK"""
+    from semiclassical_amd import potentials as P, propagators as PR
+    g = _load("hk_as5_chi002")
+    pot = P.MorsePotential(_T(g["omega"]), _T(g["chi"]), _T(g["nac"]))
+    G = _T(g["Gamma_i"])
+    prop = PR.HermanKlukPropagator(G, G, device=dev)
+    prop.initial_conditions(_T(g["q0"]), _T(g["p0"]), _T(g["Gamma_0"]), ntraj=n, generator=torch.Generator().manual_seed(7))
+    dt, E0, D = float(g["dt"]), float(g["E0"]), 5
+    wall = _timed_loop(prop, pot, dt, E0, steps, dev)
+    out = {"workload": f"anharmonic-AS 5-mode, HK, n={n} (BASELINE.json configs[0])", "n": n, "steps": steps,
+           "ms_per_step": wall / steps * 1e3, "value": n * steps / wall, "unit": "trajectory-steps/s"}
+    if n <= 10000:
+        # launch-bound: the same loop with the per-step launch sequence replayed from a HIP graph
+        wall_g = _timed_loop(prop, pot, dt, E0, steps, dev, use_graph=True)
+        out.update({"ms_per_step_graph": wall_g / steps * 1e3, "value_graph": n * steps / wall_g,
+                    "host_overhead_note": "eager: ~6 ctypes launches per step from Python; graph: one hipGraphLaunch per step"})
+    k = _kernel_ms(prop, pot, dt, E0, steps, dev)
+    nbytes = algorithmic_bytes_per_traj_step(D) * n
+    out.update({"kernel": "hk_step_w16_kernel<true>", "kernel_ms": k.get("hk_step"),
+                "roofline": {"bound": "hbm", "achieved": nbytes / (k["hk_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": nbytes / (k["hk_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}})
+    return out
+
+
+def config3(dev, n, steps):
+    """configs[2]: harmonic methylium (12 Cartesian coordinates, rank-6 Gamma_0), WM with the default cell width 1e4"""
+    from semiclassical_amd import potentials as P, propagators as PR
+    g = _load("wm_methylium")
+    pot = P.MolecularHarmonicPotential.from_arrays(g["pos0"], g["energy0"], g["grad0"], g["hess0"], g["masses"], g["nac0"],
+                                                   origin=float(g["origin"]))
+    Gi = _T(g["Gamma_i"])
+    prop = PR.WaltonManolopoulosPropagator(Gi, Gi, float(g["alpha"]), float(g["beta"]), device=dev)
+    prop.initial_conditions(_T(g["q0"]), _T(g["p0"]), _T(g["Gamma_0"]), ntraj=n, generator=torch.Generator().manual_seed(7))
+    dt, E0, D, dp = float(g["dt"]), float(g["E0"]), 12, 6
+    wall = _timed_loop(prop, pot, dt, E0, steps, dev)
+    k = _kernel_ms(prop, pot, dt, E0, steps, dev)
+    flops = wm_flops_per_traj_step(D, dp) * n
+    nbytes = (4 * D * D + 4 * D + 16) * 8 * n            # blocks, q, p, z_i, scalars and trackers of a trajectory
+    wm_ms, hk_ms = k["wm"], k["hk_step"]
+    return {"workload": f"harmonic methylium D=12 d'=6, WM alpha=beta=1e4, n={n} (BASELINE.json configs[2])", "n": n, "steps": steps,
+            "ms_per_step": wall / steps * 1e3, "value": n * steps / wall, "unit": "trajectory-steps/s",
+            "kernels_ms": {"wm_small_kernel<12,6>": wm_ms, "hk_step_kernel<true> (RK4 + HK prefactor)": hk_ms},
+            "roofline": {"kernel": "wm_small_kernel<12,6>", "bound": "fp64", "achieved": flops / (wm_ms * 1e-3) / 1e12,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (wm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": flops,
+                         "hbm_GBps": nbytes / (wm_ms * 1e-3) / 1e9, "hbm_frac": nbytes / (wm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "hk_step_roofline": {"bound": "hbm", "achieved": algorithmic_bytes_per_traj_step(D) * n / (hk_ms * 1e-3) / 1e9,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": algorithmic_bytes_per_traj_step(D) * n / (hk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+
+def config5(dev, n, steps):
+    """configs[4]: sGDML potential, 30 atoms (synthetic model of SURVEY.md section 8d: D = 90, Dd = 435, M = 200), HK"""
+    from semiclassical_amd import propagators as PR
+    from semiclassical_amd.gdml import MolecularGDMLPotential
+    from semiclassical_amd.synthetic import sgdml_model, ArrayFchk
+    N, M = 30, 200
+    model, pos = sgdml_model(N, M, 30)
+    pot0 = MolecularGDMLPotential(model, ArrayFchk(np.ones(3 * N), np.zeros(3 * N), model["z"]))
+    _, g0, _ = pot0.harmonic_approximation(torch.from_numpy(pos.reshape(-1, 1)).to(dev))
+    model["R_d_desc_alpha"] = model["R_d_desc_alpha"] * (0.02 / float(g0.abs().max()))        # molecular-size forces
+    masses = np.repeat(np.full(N, 12.0 * 1822.888), 3)
+    pot = MolecularGDMLPotential(model, ArrayFchk(masses, np.zeros(3 * N), model["z"]))
+    q0 = torch.from_numpy(pos.reshape(-1))
+    G = torch.diag(torch.full((3 * N,), 40.0))
+    prop = PR.HermanKlukPropagator(G, G, device=dev)
+    prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(7))
+    D, Dd = 3 * N, N * (N - 1) // 2
+    wall = _timed_loop(prop, pot, 2.0, 0.0, steps, dev, reps=2)
+    k = _kernel_ms(prop, pot, 2.0, 0.0, steps, dev)
+    # sGDML evaluation: three rank-M sums over (3N)^2 (6 M (3N)^2 flops), J^T products 2 x 2 M Dd 3 ... ; monodromy RK4 16 D^3
+    stage_flops = (6 * M * D * D + 8 * M * Dd * 3 + 4 * M * Dd) * n
+    mono_flops = 16 * D ** 3 * n
+    return {"workload": f"sGDML 30-atom synthetic model (D=90, M=200), HK, n={n} (BASELINE.json configs[4]: 10^4 over 8 GPUs = 1250 per GPU)",
+            "n": n, "steps": steps, "ms_per_step": wall / steps * 1e3, "value": n * steps / wall, "unit": "trajectory-steps/s",
+            "kernels_ms": {"gdml_stage_kernel (x4 per step)": k["gdml_stage"], "dense_mono_step (MFMA RK4 + prefactor)": k["dense_mono_step"]},
+            "roofline": {"kernel": "gdml_stage_kernel", "bound": "fp64", "achieved": stage_flops / (k["gdml_stage"] * 1e-3) / 1e12,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": stage_flops / (k["gdml_stage"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": stage_flops},
+            "dense_mono_roofline": {"bound": "fp64 (MFMA RK4 + scalar prefactor in one event bracket)",
+                                    "achieved": mono_flops / (k["dense_mono_step"] * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": mono_flops / (k["dense_mono_step"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}}
+
+
+def other_configs(dev):
+    out = {}
+    for key, fn, args in (("config1_n1000", config1, (1000, 100)), ("config1_n100000", config1, (100000, 50)),
+                          ("config3_wm_methylium", config3, (100000, 30)),
+                          ("config5_gdml30_share", config5, (1250, 5)), ("config5_gdml30_n10000", config5, (10000, 3))):
+        try:
+            out[key] = fn(dev, *args)
+        except Exception as err:                      # a broken side measurement must not take the headline line down
+            out[key] = {"error": f"{type(err).__name__}: {err}"}
+        torch.cuda.empty_cache()
+    return out
+
+
+def wall_to_full_ct(pot, omega, q0, dt, E0, n, dev, nt=2000):
+    """the second half of the metric: wall time of the full correlation function (nt = 2000 steps of 0.005 fs,
+    README.rst:324-327) of the headline configuration, initial conditions included"""
+    from semiclassical_amd import propagators as PR
+    G = torch.diag(omega)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    prop = PR.HermanKlukPropagator(G, G, device=dev)
+    prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(99))
+    t1 = time.perf_counter()
+    cauto, kic = prop.run(pot, dt, nt, E0)
+    wall = time.perf_counter() - t0
+    assert np.isfinite(cauto).all() and np.isfinite(kic).all() and abs(cauto[0] - 1.0) < 1e-3
+    return {"value": wall, "unit": "s", "steps": nt, "trajectories": n, "initial_conditions_s": t1 - t0,
+            "loop_s": wall - (t1 - t0), "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)]}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+
 def launch_check():
     """--launch-check: every rank joins a gloo group, proves it with one all-reduce and reports its coordinates.
     Exercises the self-launcher without a GPU and without importing the engine (tests/test_distributed.py)."""
@@ -133,7 +301,7 @@ def parse_args(argv=None):
     ap.add_argument("--ntraj-total", type=int, default=None,
                     help="trajectories of the whole job, sharded over the GPUs (default at --gpus 8: 10^6 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration lines (configs object)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration lines and the 2000-step run")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -164,6 +332,7 @@ def main():
     else:
         n = 100000 if args.ntraj is None else args.ntraj
         n_total = n * world
+
     omega, chi, nac, q0, dt = as60_model()
     dim = omega.shape[0]
     G = torch.diag(omega)
@@ -214,23 +383,31 @@ def main():
             "metric": "trajectory-steps/sec + wall-time to converged C(t), anharmonic-AS D=60",
             "value": n_total * K / wall, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3,
-            "wall_time_of_timed_loop_s": wall,       # with --steps 2000: the wall time to the full C(t) of BASELINE configs[1]
+            "wall_time_of_timed_loop_s": wall,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "anharmonic-AS 60-mode, HK, fp64, dt=0.005 fs (BASELINE.json configs[1])",
+            "config": {"workload": "anharmonic-AS 60-mode, HK, fp64, dt=0.005 fs (BASELINE.json configs[1]"
+                                   + ("; 10^6 trajectories over 8 GPUs = configs[3])" if n_total == 1000000 and world == 8 else ")"),
                        "trajectories_per_gpu": n, "trajectories_total": n_total, "dim": dim,
                        "sharding": f"{world} x {n} trajectories, one RCCL all-reduce of 4*K doubles per flush"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "hk_step_sd_kernel<4,4,true> (+ its hk_modes_kernel pre-pass, same event bracket)",
+                         "kernel": "hk_step_sd_kernel<4,4,true,true> (+ its hk_modes_kernel pre-pass, same event bracket)",
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes},
             "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
         }
         if world == 1:
+            del prop
+            torch.cuda.empty_cache()
             out["separable_shortcut"] = separable_shortcut(pot, omega, q0, dt, E0, n, K, W, dev)
-        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(omega, chi, nac, q0, dt)
+            if not args.no_configs:
+                torch.cuda.empty_cache()
+                out["wall_to_full_Ct_s"] = wall_to_full_ct(pot, omega, q0, dt, E0, n, dev)
+                torch.cuda.empty_cache()
+                out["configs"] = other_configs(dev)
+            if not args.no_cpu_baseline:          # rank 0 at N = 1 only
+                out["cpu_baseline"] = cpu_baseline(omega, chi, nac, q0, dt)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        4
+#define SC_ABI_VERSION        5
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -223,6 +223,11 @@ int sc_hk_correlate(const sc_state *st, const sc_overlap_consts *ovl_t0, const s
  * Deterministic (fixed summation order).  Either partial buffer may be NULL (its slots are left untouched). */
 int sc_reduce_slot(const double *corr_partials, int32_t n_corr, const double *energy_partials, int32_t n_energy_blocks,
                    double n_energy, double *slot, void *stream);
+
+/* The same sums into ROW *cursor of slots[.][5], then *cursor += 1 (cursor: one int64 in device memory).  With the
+ * destination held on the device a launch sequence "correlate, reduce, step" has no argument that changes from step to
+ * step: it is captured once in a HIP graph and replayed (HermanKlukPropagator.run(use_graph=True)). */
+int sc_reduce_slot_at(const double *corr_partials, int32_t n_corr, double *slots, int64_t *cursor, void *stream);
 
 /* Walton-Manolopoulos: Filinov matrix A (eqn 50), its inverse and determinant, Gt/Gti/CQQ/M (57-78), the second
  * inverse and determinant, the trackers of sqrt(detA), sqrt(detM) and the per-trajectory terms of eqns (85), (100),

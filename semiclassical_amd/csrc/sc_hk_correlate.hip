@@ -153,6 +153,7 @@ struct ReduceArgs {
     int nen;
     double n_energy;
     double *slot;
+    long long *cursor;      // optional device-resident row counter: the sums go to slot + 5 * (*cursor), then ++(*cursor)
 };
 
 __global__ __launch_bounds__(256) void reduce_slot_kernel(ReduceArgs A) {
@@ -165,8 +166,10 @@ __global__ __launch_bounds__(256) void reduce_slot_kernel(ReduceArgs A) {
         for (int i = threadIdx.x; i < A.nen; i += blockDim.x) v[4] += A.epart[i];
     block_sum<5>(v, red);
     if (threadIdx.x == 0) {
-        if (A.cpart) for (int k = 0; k < 4; ++k) A.slot[k] = v[k];
-        if (A.epart) A.slot[4] = v[4] / A.n_energy;
+        double *slot = A.slot;
+        if (A.cursor) { slot += 5 * *A.cursor; *A.cursor += 1; }
+        if (A.cpart) for (int k = 0; k < 4; ++k) slot[k] = v[k];
+        if (A.epart) slot[4] = v[4] / A.n_energy;
     }
 }
 
@@ -267,9 +270,16 @@ extern "C" int sc_hk_correlate(const sc_state *st, const sc_overlap_consts *ovl_
 extern "C" int sc_reduce_slot(const double *corr_partials, int32_t n_corr, const double *energy_partials,
                               int32_t n_energy_blocks, double n_energy, double *slot, void *stream) {
     if (!slot) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_reduce_slot: null slot");
-    ReduceArgs a{corr_partials, n_corr, energy_partials, n_energy_blocks, n_energy, slot};
+    ReduceArgs a{corr_partials, n_corr, energy_partials, n_energy_blocks, n_energy, slot, nullptr};
     hipLaunchKernelGGL(reduce_slot_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return sc_check_launch("sc_reduce_slot");
+}
+
+extern "C" int sc_reduce_slot_at(const double *corr_partials, int32_t n_corr, double *slots, int64_t *cursor, void *stream) {
+    if (!slots || !cursor || !corr_partials) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_reduce_slot_at: null argument");
+    ReduceArgs a{corr_partials, n_corr, nullptr, 0, 1.0, slots, (long long *)cursor};
+    hipLaunchKernelGGL(reduce_slot_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    return sc_check_launch("sc_reduce_slot_at");
 }
 
 extern "C" int sc_energy_guard(const double *energy_partials, int32_t n_blocks, double n_traj, double *elog,

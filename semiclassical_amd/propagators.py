@@ -212,6 +212,17 @@ class HermanKlukPropagator(object):
         self._launch_step(potential, float(dt))
         self.t += float(dt)
 
+    # ---- optional per-kernel timing (bench.py): HIP events on the launch stream around labelled launches ----
+    kernel_timing = False
+
+    def _timed(self, label):
+        return _KernelTimer(self, label) if self.kernel_timing else _NO_TIMER
+
+    def kernel_times_ms(self):
+        """{label: [duration of every launch recorded while ``kernel_timing`` was set]}; synchronises"""
+        torch.cuda.current_stream(self.device).synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.__dict__.get("_kernel_events", {}).items()}
+
     def _launch_step(self, potential, dt, desc=None, remembered=False):
         """``desc`` / ``remembered``: run() resolves the potential's device descriptor and coupling constants once per
         call instead of once per step"""
@@ -239,7 +250,8 @@ class HermanKlukPropagator(object):
             else:
                 self._sync_dense_mono(leave_diagonal=True)
                 self._set_mono_layout(self._fast_path_layout(desc))
-                check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
+                with self._timed("hk_step"):
+                    check(lib.sc_hk_step(desc, self._state, self._hk, dt, 0, ptr(self._epart), s))
             nblocks = self._gstep
         if timed:
             e1.record()
@@ -284,9 +296,11 @@ class HermanKlukPropagator(object):
         with torch.cuda.device(self.device):
             model = potential._gdml_model(self.device)
         for stage in range(4):
-            check(lib.sc_gdml_stage(model, self._state, self._dense, dt, stage, ptr(self._epart), s))
-        check(lib.sc_dense_mono_step(self._state, self._hk, model.inv_mass, ptr(self._dense_bufs[0]), self._mono_sums_ptr(),
-                                     dt, 0, s))
+            with self._timed("gdml_stage"):
+                check(lib.sc_gdml_stage(model, self._state, self._dense, dt, stage, ptr(self._epart), s))
+        with self._timed("dense_mono_step"):
+            check(lib.sc_dense_mono_step(self._state, self._hk, model.inv_mass, ptr(self._dense_bufs[0]),
+                                         self._mono_sums_ptr(), dt, 0, s))
         return self._gdense
 
     def _dense_scratch(self):
@@ -394,7 +408,14 @@ class HermanKlukPropagator(object):
     def _mc_norm(self):
         return self._ntraj_norm * (2 * np.pi * hbar) ** self.dim
 
-    def _launch_correlate(self, slot_ptr, per_trajectory=True):
+    def _reduce_into(self, partials, count, slot_ptr, cursor):
+        """sums of the per-workgroup partials into the slot at `slot_ptr`, or into row *cursor of the slot buffer"""
+        if cursor is None:
+            check(lib.sc_reduce_slot(ptr(partials), count, None, 0, 1.0, C_void(slot_ptr), self._stream()))
+        else:
+            check(lib.sc_reduce_slot_at(ptr(partials), count, C_void(slot_ptr), ptr(cursor), self._stream()))
+
+    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None):
         """per-trajectory terms + their sums for the current state into the 5-double slot at `slot_ptr`"""
         s = self._stream()
         nac = self._nac
@@ -402,7 +423,7 @@ class HermanKlukPropagator(object):
                                   ptr(self._nacq) if nac is not None else None, self._mc_norm(),
                                   ptr(self._cq) if per_trajectory else None,
                                   ptr(self._kq) if per_trajectory else None, ptr(self._cpart), s))
-        check(lib.sc_reduce_slot(ptr(self._cpart), self._gcorr, None, 0, 1.0, C_void(slot_ptr), s))
+        self._reduce_into(self._cpart, self._gcorr, slot_ptr, cursor)
 
     def _correlate_current(self, need_nac):
         if self._corr_step == self._nsteps and (self._corr_has_nac or not need_nac):
@@ -430,12 +451,17 @@ class HermanKlukPropagator(object):
         k = complex(self._slot_host[2], self._slot_host[3])
         return k * np.exp(1j / hbar * self.t * energy0_es)
 
-    def run(self, potential, dt, nt, energy0_es=0.0, slots=None):
+    def run(self, potential, dt, nt, energy0_es=0.0, slots=None, use_graph=False):
         """The caller loop of cli.py:401-436 on the device: ``nt`` times (C_auto, k_ic, step), no host sync.
 
         Returns ``(autocorrelation[nt], ic_correlation[nt])`` as complex NumPy arrays.  With ``slots`` (a
         device tensor (nt, 5)) the raw sums are left on the device for a later flush (see distributed.py)
         and ``None`` is returned.
+
+        ``use_graph``: for small batches the loop is bound by the ~6 kernel launches per step, not by the kernels.
+        The first iteration then runs as usual and the launch sequence of the second one is captured in a HIP graph
+        that is replayed for the remaining steps (the row of ``slots`` a step writes is a device-resident cursor, so
+        no kernel argument changes between steps).  Only for the fused kernels (device potential descriptor, D <= 64).
         """
         assert self.dim == potential.dimensions(), "potential has wrong dimensions"
         dt = float(dt)
@@ -449,15 +475,42 @@ class HermanKlukPropagator(object):
         base = slots.data_ptr()
         fused = hasattr(potential, "_descriptor") and not hasattr(potential, "_gdml_model") and self.dim <= 64
         desc = self._potential_descriptor(potential) if fused else None
-        for k in range(nt):
-            self._launch_correlate(base + 40 * k, per_trajectory=False)
-            self._launch_step(potential, dt, desc=desc, remembered=True)
-            self.t += dt
+        if use_graph and fused and nt > 2 and not getattr(self, "profile_step_kernel", False) and not self.kernel_timing:
+            self._run_graph(potential, dt, nt, desc, slots)
+        else:
+            for k in range(nt):
+                self._launch_correlate(base + 40 * k, per_trajectory=False)
+                self._launch_step(potential, dt, desc=desc, remembered=True)
+                self.t += dt
         self._corr_step = -1
         if not own:
             return None
         self.synchronize()
         return self.finalize_slots(slots, t0, dt, energy0_es)
+
+    def _run_graph(self, potential, dt, nt, desc, slots):
+        """first iteration eagerly (lazy set-up, layout conversion), then one captured iteration replayed nt - 1 times"""
+        base = slots.data_ptr()
+        cursor = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+        def iteration():
+            self._launch_correlate(base, per_trajectory=False, cursor=cursor)
+            self._launch_step(potential, dt, desc=desc, remembered=True)
+        iteration()
+        graph = torch.cuda.CUDAGraph()
+        steps_before = self._nsteps
+        with torch.cuda.graph(graph):
+            iteration()                      # recorded, not executed
+        self._nsteps = steps_before + 1      # the host-side bookkeeping of a captured iteration ran once ...
+        graph.replay()
+        for _ in range(nt - 2):
+            graph.replay()
+            self._nsteps += 1                # ... and is repeated here for every further replay
+        for _ in range(nt):
+            self.t += dt                      # accumulated as the reference's loop does (propagators.py:655)
+        if hasattr(self, "_wm_step"):
+            self._wm_step = self._nsteps      # the WM terms of the current state were produced by the last replay
+        self._graph = graph                  # keeps the captured launch parameters alive until the work has run
 
     def _check_slots(self, slots, nt):
         """the kernels write 5 doubles at slots + 40 k for k < nt: refuse anything that is not exactly that buffer"""
@@ -604,6 +657,31 @@ class HermanKlukPropagator(object):
                 for name, (s, z) in self._TRACKED.items()}
 
 
+class _KernelTimer(object):
+    def __init__(self, prop, label):
+        self.prop, self.label = prop, label
+
+    def __enter__(self):
+        self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        self.prop.__dict__.setdefault("_kernel_events", {}).setdefault(self.label, []).append((self.e0, self.e1))
+        return False
+
+
+class _NoTimer(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+
+
 def C_void(address):
     import ctypes
     return ctypes.c_void_p(int(address))
@@ -680,9 +758,10 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
 
     def _wm_launch(self, track):
         has_nac = self._wm_nac_bufs is not None
-        check(lib.sc_wm_correlate(self._state, self._wm, ptr(self._zi_t), ptr(self.probi), self._mc_norm(),
-                                  track, int(has_nac), ptr(self._cq), ptr(self._kq), ptr(self._wpart),
-                                  self._stream()))
+        with self._timed("wm"):
+            check(lib.sc_wm_correlate(self._state, self._wm, ptr(self._zi_t), ptr(self.probi), self._mc_norm(),
+                                      track, int(has_nac), ptr(self._cq), ptr(self._kq), ptr(self._wpart),
+                                      self._stream()))
         self._wm_step, self._wm_has_nac = self._nsteps, has_nac
 
     def _after_prefactor(self, track):
@@ -737,12 +816,12 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         check(lib.sc_reduce_slot(ptr(partials), int(tiles), None, 0, 1.0, ptr(slot), s))
         return float(torch.sqrt(slot[0]).item())
 
-    def _launch_correlate(self, slot_ptr, per_trajectory=True):
+    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None):
         # the per-trajectory terms were produced together with the prefactor; recompute (with the stored branch
         # signs, no tracking) only if the coupling vector was not known at that time
         if self._wm_step != self._nsteps or (self._wm_nac_bufs is not None and not self._wm_has_nac):
             self._wm_launch(0)
-        check(lib.sc_reduce_slot(ptr(self._wpart), self._gwm, None, 0, 1.0, C_void(slot_ptr), self._stream()))
+        self._reduce_into(self._wpart, self._gwm, slot_ptr, cursor)
 
     def _correlate_current(self, need_nac):
         if self._corr_step == self._nsteps and (self._corr_has_nac or not need_nac):

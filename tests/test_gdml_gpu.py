@@ -74,24 +74,11 @@ def test_hk_on_gdml_surface_matches_reference_golden():
 
 
 def synthetic_model(n_atoms, n_train, seed):
-    """an sGDML model of the right shapes for a molecule the reference ships no model for (SURVEY.md section 8d,
-    config 5: 30 atoms): atoms on a jittered lattice, training descriptors = descriptors of perturbed geometries,
-    coefficients scaled like the coumarin model's"""
-    rng = np.random.default_rng(seed)
-    side = int(np.ceil(n_atoms ** (1 / 3)))
-    grid = np.array([(i, j, k) for i in range(side) for j in range(side) for k in range(side)], dtype=float)[:n_atoms]
-    pos = 2.6 * grid + rng.normal(0, 0.15, grid.shape)
-    k, l = np.tril_indices(n_atoms, -1)
-    desc = lambda p: 1.0 / np.linalg.norm(p[k] - p[l], axis=1)
-    R_desc = np.stack([desc(pos + rng.normal(0, 0.08, pos.shape)) for _ in range(n_train)], axis=1)      # (Dd, M)
-    alpha = rng.normal(0, 2.0e7, (n_train, len(k))) * R_desc.T ** 2
-    model = {"sig": np.int64(40), "c": np.float64(-3.2), "std": np.float64(0.07), "z": np.full(n_atoms, 6),
-             "R_desc": R_desc, "R_d_desc_alpha": alpha, "perms": np.arange(n_atoms)[None, :],
-             "tril_perms_lin": np.arange(len(k))}
-    return model, pos
+    from semiclassical_amd.synthetic import sgdml_model
+    return sgdml_model(n_atoms, n_train, seed)
 
 
-TOL30 = (1e-10, 1e-7, 1e-7, 1e-6, 1e-6)       # E, grad, hess, y, c2 (tightened below the achieved figures x 3 once measured)
+TOL30 = (1e-12, 1e-12, 1e-12, 1e-12, 1e-11)      # E, grad, hess, y, c2; achieved 0, 1.1e-15, 1.6e-15, 2.1e-16, 1.5e-14 (well-conditioned model)
 
 
 def test_gdml_30_atoms_matches_oracle():

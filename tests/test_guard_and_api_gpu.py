@@ -13,6 +13,7 @@ import torch
 from tests import cases
 
 pytestmark = pytest.mark.gpu
+torch.set_default_dtype(torch.float64)          # the oracle follows the reference's global default (cli.py:121)
 
 
 def _energies(g, nsteps, pot=None, orc_pot=None):
@@ -122,3 +123,23 @@ def test_constants_follow_in_place_changes_of_the_potential():
                                 cases.T(g["probi"]))
     c, k = prop.run(pot, dt, 6, E0)
     assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["hk_as5_chi002", "hk_as60", "wm_methylium", "wm_as5_chi002", "hk_methylium"])
+def test_graph_replay_equals_eager_loop(name):
+    """run(use_graph=True): one captured iteration replayed (device-resident slot cursor) gives bit-identical
+    correlation functions and state, and leaves the propagator usable step by step afterwards"""
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load(name)
+    pot = engine_potential(g)
+    dt, E0, nt = float(g["dt"]), float(g["E0"]), int(g["nt"])
+    a, b = engine_propagator(g), engine_propagator(g)
+    ca, ka = a.run(pot, dt, nt, E0)
+    cb, kb = b.run(pot, dt, nt, E0, use_graph=True)
+    assert np.array_equal(ca, cb) and np.array_equal(ka, kb)
+    assert cases.rel_err(cb, g["cauto"]) < 1e-8 and cases.rel_err(kb, g["kic"]) < 1e-8
+    assert torch.equal(a.y, b.y) and torch.equal(a._c2, b._c2) and a.t == b.t and a._nsteps == b._nsteps
+    assert a.autocorrelation(E0) == b.autocorrelation(E0)
+    a.step(pot, dt); b.step(pot, dt)
+    assert a.ic_correlation(pot, E0) == b.ic_correlation(pot, E0)
+    assert abs(a.mean_energy() - b.mean_energy()) == 0.0
