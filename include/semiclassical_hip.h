@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        5
+#define SC_ABI_VERSION        6
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -161,6 +161,11 @@ typedef struct sc_gdml_model {
     const int32_t *pair_k, *pair_l;
     double q, c, std, origin;
     const double *inv_mass;     /* [3 n_atoms] */
+    /* the same training data in SQUARE form, rows of row_len = sc_gdml_row_len(n_atoms) doubles (n_atoms <= 32):
+     *   xs_sq[m][a][c] = xs_train[m][pair(a, c)],  a_sq[m][a][c] = jx_alphas[m][pair(a, c)],  0 for c = a and c >= n_atoms
+     * (the J^T products of the Hessian read one contiguous row per atom and training point instead of gathering) */
+    const double *xs_sq, *a_sq;
+    int32_t row_len, _pad2;
 } sc_gdml_model;
 
 /* per-trajectory scratch of the unfused RK4 step for dense, position-dependent Hessians */
@@ -244,6 +249,9 @@ int64_t sc_wm_scratch_bytes(int64_t n, int32_t dim, int32_t dprime);
 int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi, const double *probi,
                     double mc_norm, int32_t track, int32_t has_nac, double *cq_out, double *kq_out,
                     double *partials, void *stream);
+
+/* row length of the square-form training arrays for a molecule of n_atoms atoms (8, 16, 20, 24 or 32; -1 beyond 32) */
+int sc_gdml_row_len(int32_t n_atoms);
 
 /* E - origin [n], dE/dr [n][3N], d2E/drdr [n][3N][3N] of the sGDML model at the geometries r [n][3N].
  * Replaces GDMLPredict.forward / MolecularGDMLPotential.harmonic_approximation (gdml_predictor.py:96-250). */

@@ -23,7 +23,11 @@
 //   hess = std [ sum_m w_m XJ_m XJ_m^T - e_m (AJ_m XJ_m^T + XJ_m AJ_m^T) - (sum_m e_m XA_m) J^T J + sum_d g_x[d] d2x_d ]
 //   with w_m = e_m XA_m q / d_m, XJ_m = J^T xd_m, AJ_m = J^T A_m.  The Jacobian row of pair d = (k, l) is
 //   jd = -x_d^3 (r_k - r_l) on atom k and -jd on atom l, so J^T v is a gather over the N-1 partners of an atom,
-//   J^T J and the second-derivative term are 3x3 blocks per atom pair.  Everything is organised by atom-pair blocks.
+//   J^T J and the second-derivative term are 3x3 blocks per atom pair.
+// The three rank-M sums are ONE GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): with Z_m = w_m XJ_m - e_m AJ_m
+//   sum_m w_m XJ_m XJ_m^T - e_m (AJ_m XJ_m^T + XJ_m AJ_m^T) = [XJ ; -e AJ]^T [Z ; XJ]        (3N x 2M times 2M x 3N)
+// accumulated per chunk of training points from LDS operands, one 16 x 16 tile of the upper triangle per accumulator
+// (tiles dealt round-robin to the wavefronts); the atom-pair terms are added to the accumulators element by element.
 #include "sc_common.h"
 #include "sc_prefactor.h"
 
@@ -34,11 +38,20 @@ __device__ __forceinline__ int pair_index(int a, int b) {      // a != b; torch.
 }
 
 struct GdmlLds {
-    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *XJ, *AJ, *xsL, *aL, *red;
+    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *P, *Qn, *Z, *dg, *xsL, *aL, *red;
+    int XP;      // row stride of the MFMA operand arrays P = XJ, Qn = -e AJ, Z = w XJ - e AJ  ([chunk][XP])
 };
 
+#define GDML_MAX_TILES 6      // 16 x 16 accumulator tiles per wavefront (21 tiles of a 30-atom molecule on 4 wavefronts)
+
+// row stride of the operand arrays: 16 T (+16) doubles with stride = 16 mod 32, so that the four rows an MFMA operand
+// read touches (64 lanes x 8 bytes) fall into different LDS banks
+__host__ __device__ inline int gdml_xp(int N) {
+    const int T = (3 * N + 15) / 16;
+    return (T & 1) ? 16 * T : 16 * T + 16;
+}
+
 #define GDML_CHUNK_MAX 16     // training points staged per chunk (run-time choice: 16, 8 or 4, by the LDS budget)
-#define GDML_NB 2            // atom-pair blocks of the Hessian per thread and group
 
 __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt, int chunk) {
     GdmlLds L;
@@ -52,21 +65,26 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt, int chunk) {
     L.em = f;   f += Mt;
     L.wm = f;   f += Mt;
     L.ea = f;   f += Mt;
-    L.grad = f; f += 3 * N;
-    L.XJ = f;   f += chunk * 3 * N;
-    L.AJ = f;   f += chunk * 3 * N;
-    L.xsL = f;  f += chunk * Dd;       // training descriptors / coefficients of the chunk: staged once (coalesced),
-    L.aL = f;   f += chunk * Dd;       // then read 2 (N-1) times each by the J^T products
+    L.grad = f; f += 3 * N + (N & 1);
+    L.dg = f;   f += 9 * N + (N & 1);
+    L.XP = gdml_xp(N);
+    L.P = f;                           // operand arrays of the Hessian products; before that phase the same
+    L.Qn = f + chunk * L.XP;           // storage holds the per-wavefront partial sums of the descriptor gradient
+    L.Z = f + 2 * chunk * L.XP;        // (8 rows of Dd)
+    L.xsL = f;
+    L.aL = f;
     return L;
 }
 
 size_t gdml_lds_doubles(int N, int Dd, int Mt, int chunk) {
-    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + 2 * (size_t)chunk * 3 * N +
-           2 * (size_t)chunk * Dd;
+    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + (N & 1) + 9 * N + (N & 1) +
+           (3 * (size_t)chunk * gdml_xp(N) > 8 * (size_t)Dd ? 3 * (size_t)chunk * gdml_xp(N) : 8 * (size_t)Dd);
 }
 
 // V (without origin), grad[3N] (LDS, L.grad) and hess[3N][3N] (global, row-major) at the geometry in L.pos.
 // Every thread returns the energy.
+// HN = partner atoms per half row of the square-form training data (rows of 2 HN doubles, sc_gdml_model.row_len)
+template <int HN>
 __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess, int chunk) {
     const int N = G.n_atoms, Dd = G.n_desc, Mt = G.n_train, X = 3 * N;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
@@ -115,7 +133,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     __syncthreads();
     // ---- gradient in descriptor space, then Cartesian gradient
     // every wavefront takes a slice of the training points (lanes over the descriptor: coalesced rows), the per-wave
-    // partial sums meet in LDS (L.xsL and L.aL are contiguous and free at this point: 2 * chunk >= 2 * nw rows of Dd)
+    // partial sums meet in LDS (L.xsL = the storage of the Hessian operand arrays, not yet in use: one row of Dd per wavefront)
     for (int d0 = 0; d0 < Dd; d0 += 64) {
         const int d = d0 + lane;
         if (d < Dd) {
@@ -129,8 +147,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                 comp += fabs(g) >= fabs(t) ? (g - s) + t : (t - s) + g;
                 g = s;
             }
-            L.xsL[wave * Dd + d] = g;
-            L.xsL[(nw + wave) * Dd + d] = comp;
+            L.xsL[wave * Dd + d] = g + comp;
         }
     }
     __syncthreads();
@@ -139,7 +156,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         for (int w = 0; w < nw; ++w) {
             const double t = L.xsL[w * Dd + d];
             const double s = g + t;
-            comp += (fabs(g) >= fabs(t) ? (g - s) + t : (t - s) + g) + L.xsL[(nw + w) * Dd + d];
+            comp += fabs(g) >= fabs(t) ? (g - s) + t : (t - s) + g;
             g = s;
         }
         L.gx[d] = g + comp;
@@ -156,141 +173,133 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         }
         L.grad[xi] = g * G.std;
     }
-    // ---- Hessian by atom-pair blocks (a <= b).  A thread owns up to GDML_NB blocks of a group, so that the chunk
-    // products J^T xd_m, J^T A_m are formed once per group of GDML_NB * blockDim blocks (once in all for N <= 31).
-    const int nblk = N * (N + 1) / 2;
-    auto finish_block = [&](double (&h)[3][3], int a, int b) {
-        // - S J^T J + second derivatives of the descriptor
-        if (a != b) {
-            const int d = pair_index(a, b);          // b > a: b is the "k" atom of the pair
-            const double x = L.x[d], g = L.gx[d];
-            const double jx = L.jd[3 * d], jy = L.jd[3 * d + 1], jz = L.jd[3 * d + 2];
-            const double jv[3] = {jx, jy, jz};
-            // diff = r_k - r_l = -jd / x^3
-            const double ix3 = -1.0 / (x * x * x);
-            const double df[3] = {jx * ix3, jy * ix3, jz * ix3};
-            const double x5 = x * x * x * x * x, x3 = x * x * x;
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-#pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
-                    h[u][v] += S * jv[u] * jv[v] - T;          // J^T J block is -jd jd^T
-                }
-        } else {
-            for (int c = 0; c < N; ++c) {
-                if (c == a) continue;
-                const int d = pair_index(a, c);
-                const double x = L.x[d], g = L.gx[d];
-                const double jv[3] = {L.jd[3 * d], L.jd[3 * d + 1], L.jd[3 * d + 2]};
-                const double ix3 = -1.0 / (x * x * x);
-                const double df[3] = {jv[0] * ix3, jv[1] * ix3, jv[2] * ix3};
-                const double x5 = x * x * x * x * x, x3 = x * x * x;
-#pragma unroll
-                for (int u = 0; u < 3; ++u)
-#pragma unroll
-                    for (int v = 0; v < 3; ++v) {
-                        const double T = 3.0 * g * x5 * df[u] * df[v] - (u == v ? g * x3 : 0.0);
-                        h[u][v] += -S * jv[u] * jv[v] + T;
-                    }
-            }
+    // ---- Hessian.  Diagonal atom blocks of the pair terms first: dg[a] = sum_c (-S jd jd^T + d2x) over the partners
+    for (int e = tid; e < 9 * N; e += nth) {
+        const int a = e / 9, u = (e - 9 * a) / 3, v = e - 9 * a - 3 * u;
+        double acc = 0.0;
+        for (int c = 0; c < N; ++c) {
+            if (c == a) continue;
+            const int d = pair_index(a, c);
+            const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x, ix3 = -1.0 / x3;
+            const double ju = L.jd[3 * d + u], jv = L.jd[3 * d + v];
+            acc += -S * ju * jv + 3.0 * g * x5 * (ju * ix3) * (jv * ix3) - (u == v ? g * x3 : 0.0);
         }
+        L.dg[e] = acc;
+    }
+    // rank-M sums on the matrix cores.  Tile t = c (c + 1) / 2 + r, r <= c, of the upper triangle belongs to wavefront
+    // t % nw; accumulator layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int XP = L.XP, T = (X + 15) / 16, ntiles = T * (T + 1) / 2, rg = lane >> 4, li = lane & 15;
+    d4 acc[GDML_MAX_TILES];
+    int tr_[GDML_MAX_TILES], tc_[GDML_MAX_TILES];
 #pragma unroll
-        for (int u = 0; u < 3; ++u)
+    for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
+        acc[sl] = (d4){0.0, 0.0, 0.0, 0.0};
+        const int t = wave + sl * nw;
+        int c = 0;
+        while ((c + 1) * (c + 2) / 2 <= t) ++c;
+        tr_[sl] = t - c * (c + 1) / 2; tc_[sl] = c;
+    }
+    for (int e = tid; e < 3 * chunk * XP; e += nth) L.P[e] = 0.0;       // P, Qn, Z are contiguous: padding columns stay 0
+    // formation roles: thread = (training point slot, atom, half of the partner atoms)
+    const int fm_rows = nth / (2 * N) < chunk ? nth / (2 * N) : chunk;      // training points formed per pass
+    const int fm_half = tid & 1, fm_at = (tid >> 1) % N, fm_mm = (tid >> 1) / N;
+    const bool fm_active = fm_mm < fm_rows;
+    double coef[3][HN], base[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const double val = h[u][v] * G.std;
-                hess[(size_t)(3 * a + u) * X + 3 * b + v] = val;
-                hess[(size_t)(3 * b + v) * X + 3 * a + u] = val;
-            }
-    };
-    for (int blk0 = 0; blk0 < nblk; blk0 += GDML_NB * nth) {
-        int ba[GDML_NB], bb[GDML_NB];
-        bool own[GDML_NB];
-        double h[GDML_NB][3][3];
+    for (int cc = 0; cc < HN; ++cc) {
+        const int c = HN * fm_half + cc;
+        const bool ok = c < N && c != fm_at;
+        const int d = ok ? pair_index(fm_at, c) : 0;
+        const double xq = ok ? L.x[d] : 0.0;
 #pragma unroll
-        for (int sl = 0; sl < GDML_NB; ++sl) {
-            const int blk = blk0 + sl * nth + tid;
-            own[sl] = blk < nblk;
-            int a = 0, b = 0;
-            if (own[sl]) {   // blk = b (b+1)/2 + a with a <= b
-                b = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
-                while (b * (b + 1) / 2 > blk) --b;
-                while ((b + 1) * (b + 2) / 2 <= blk) ++b;
-                a = blk - b * (b + 1) / 2;
-            }
-            ba[sl] = a; bb[sl] = b;
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-#pragma unroll
-                for (int v = 0; v < 3; ++v) h[sl][u][v] = 0.0;
+        for (int u = 0; u < 3; ++u) {
+            const double j = ok ? ((fm_at > c) ? L.jd[3 * d + u] : -L.jd[3 * d + u]) : 0.0;
+            coef[u][cc] = j;
+            base[u] = fma(j, xq, base[u]);
         }
-        for (int m0 = 0; m0 < Mt; m0 += chunk) {
-            const int mc = min(chunk, Mt - m0);
-            __syncthreads();
-            // the chunk's training rows m0 .. m0+mc-1 are contiguous: coalesced global -> LDS.  (Read straight from L2
-            // by the J^T products they cost 8 scattered bytes per multiply-add: the launch was L2-bandwidth bound.)
-            for (int e = tid; e < mc * Dd; e += nth) {
-                L.xsL[e] = G.xs_train[(size_t)m0 * Dd + e];
-                L.aL[e] = G.jx_alphas[(size_t)m0 * Dd + e];
-            }
-            __syncthreads();
-            // XJ_m = J^T xd_m, AJ_m = J^T A_m for the chunk.  Thread = (Cartesian component xi, group g of training
-            // points mm = g, g + NG, ...): the Jacobian entry of a partner atom is fetched once per group, not per m.
-            {
-                const int NG = nth / X > 0 ? nth / X : 1;             // groups of training points
-                constexpr int MPT = 4;                                // training points per thread and pass
-                if (tid < NG * X) {
-                    const int xi = tid % X, g = tid / X, at = xi / 3, u = xi - 3 * at;
-                    for (int mb = g; mb < mc; mb += NG * MPT) {
-                        double sx[MPT], sa[MPT];
+    }
 #pragma unroll
-                        for (int i = 0; i < MPT; ++i) { sx[i] = 0.0; sa[i] = 0.0; }
-                        for (int c = 0; c < N; ++c) {
-                            if (c == at) continue;
-                            const int d = pair_index(at, c);
-                            const double j = (at > c) ? L.jd[3 * d + u] : -L.jd[3 * d + u];
-                            const double xd = L.x[d];
+    for (int u = 0; u < 3; ++u) base[u] += dpp_mov_f64<0xB1>(base[u]);    // both halves of the partner sum
+    for (int m0 = 0; m0 < Mt; m0 += chunk) {
+        const int mc = min(chunk, Mt - m0);
+        __syncthreads();
+        // XJ_m = J^T xd_m, AJ_m = J^T A_m for the chunk, from the SQUARE form of the training data
+        //   xs_sq[m][a][c] = xs_m[pair(a, c)],  a_sq[m][a][c] = A_m[pair(a, c)]   (rows of 32 doubles, zero for c = a, c >= N)
+        // read straight from L2 (the rows of one atom are contiguous): a thread pair (half = 0, 1) owns (atom a, training
+        // point mm), each half takes 16 partner atoms with its coefficients coef[u][c] = +-jd[pair(a, c)][u] in
+        // registers (loaded once per geometry), so a training value feeds three multiply-adds and nothing is gathered:
+        //   XJ_m[a, u] = base[u] - sum_c coef[u][c] xs_sq[m][a][c],   AJ_m[a, u] = sum_c coef[u][c] a_sq[m][a][c]
+        if (mc < chunk)                                  // last, partial chunk: its unused operand rows must be zero
+            for (int e = mc * XP + tid; e < chunk * XP; e += nth) { L.P[e] = 0.0; L.Qn[e] = 0.0; L.Z[e] = 0.0; }
+#ifndef GDML_ABLATE_FORM
+        for (int pass = 0; pass < chunk; pass += fm_rows) {
+            const int mm = pass + fm_mm;
+            double sx[3] = {0.0, 0.0, 0.0}, sa[3] = {0.0, 0.0, 0.0};
+            if (fm_active && mm < mc) {
+                const size_t row = (((size_t)(m0 + mm) * N + fm_at) * (2 * HN) + HN * fm_half);
+                const double2 *xr = (const double2 *)(G.xs_sq + row), *ar = (const double2 *)(G.a_sq + row);
+                double2 xv[HN / 2], av[HN / 2];
 #pragma unroll
-                            for (int i = 0; i < MPT; ++i) {
-                                const int mm = mb + i * NG;
-                                if (mm < mc) {
-                                    sx[i] = fma(j, xd - L.xsL[mm * Dd + d], sx[i]);
-                                    sa[i] = fma(j, L.aL[mm * Dd + d], sa[i]);
-                                }
-                            }
-                        }
+                for (int i = 0; i < HN / 2; ++i) { xv[i] = xr[i]; av[i] = ar[i]; }
 #pragma unroll
-                        for (int i = 0; i < MPT; ++i) {
-                            const int mm = mb + i * NG;
-                            if (mm < mc) { L.XJ[mm * X + xi] = sx[i]; L.AJ[mm * X + xi] = sa[i]; }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int sl = 0; sl < GDML_NB; ++sl) {
-                if (!own[sl]) continue;
-                const int a = ba[sl], b = bb[sl];
-                for (int mm = 0; mm < mc; ++mm) {
-                    const double w = L.wm[m0 + mm], e = L.em[m0 + mm];
-                    const double *xj = L.XJ + mm * X, *aj = L.AJ + mm * X;
+                for (int i = 0; i < HN / 2; ++i) {
 #pragma unroll
                     for (int u = 0; u < 3; ++u) {
-                        const double xa = xj[3 * a + u], aa = aj[3 * a + u];
-#pragma unroll
-                        for (int v = 0; v < 3; ++v) {
-                            const double xb = xj[3 * b + v], ab = aj[3 * b + v];
-                            h[sl][u][v] += w * xa * xb - e * (aa * xb + xa * ab);
-                        }
+                        sx[u] = fma(coef[u][2 * i], xv[i].x, sx[u]); sx[u] = fma(coef[u][2 * i + 1], xv[i].y, sx[u]);
+                        sa[u] = fma(coef[u][2 * i], av[i].x, sa[u]); sa[u] = fma(coef[u][2 * i + 1], av[i].y, sa[u]);
                     }
                 }
             }
-        }
+            // the two halves of a row sit in adjacent lanes
 #pragma unroll
-        for (int sl = 0; sl < GDML_NB; ++sl)
-            if (own[sl]) finish_block(h[sl], ba[sl], bb[sl]);
+            for (int u = 0; u < 3; ++u) { sx[u] += dpp_mov_f64<0xB1>(sx[u]); sa[u] += dpp_mov_f64<0xB1>(sa[u]); }   // quad_perm [1,0,3,2]
+            if (fm_active && fm_half == 0 && mm < mc) {
+                const double w = L.wm[m0 + mm], em = L.em[m0 + mm];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const double xj = base[u] - sx[u], q = -em * sa[u];
+                    L.P[mm * XP + 3 * fm_at + u] = xj; L.Qn[mm * XP + 3 * fm_at + u] = q; L.Z[mm * XP + 3 * fm_at + u] = fma(w, xj, q);
+                }
+            }
+        }
+#endif
+        __syncthreads();
+#ifndef GDML_ABLATE_MFMA
+#pragma unroll
+        for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
+            if (wave + sl * nw >= ntiles) continue;               // wave-uniform
+            const double *ar = L.P + rg * XP + 16 * tr_[sl] + li, *bc = L.Z + rg * XP + 16 * tc_[sl] + li;
+            const double *aq = L.Qn + rg * XP + 16 * tr_[sl] + li, *bp = L.P + rg * XP + 16 * tc_[sl] + li;
+            for (int ks = 0; ks < chunk / 4; ++ks) {
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks * XP], bc[4 * ks * XP], acc[sl], 0, 0, 0);
+                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[4 * ks * XP], bp[4 * ks * XP], acc[sl], 0, 0, 0);
+            }
+        }
+#endif
+    }
+    __syncthreads();         // dg complete (written before the chunk loop's first barrier anyway)
+    // atom-pair terms element by element, scale, write both triangles
+#pragma unroll
+    for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
+        if (wave + sl * nw >= ntiles) continue;
+        const int y = 16 * tc_[sl] + li, b = y / 3, v = y - 3 * b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xr = 16 * tr_[sl] + rg + 4 * q, a = xr / 3, u = xr - 3 * a;
+            if (xr >= X || y >= X || (tr_[sl] == tc_[sl] && xr > y)) continue;
+            double fin;
+            if (a == b) fin = L.dg[9 * a + 3 * u + v];
+            else {
+                const int d = pair_index(a, b);
+                const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x, ix3 = -1.0 / x3;
+                const double ju = L.jd[3 * d + u], jv = L.jd[3 * d + v];
+                fin = S * ju * jv - (3.0 * g * x5 * (ju * ix3) * (jv * ix3) - (u == v ? g * x3 : 0.0));
+            }
+            const double val = (acc[sl][q] + fin) * G.std;
+            hess[(size_t)xr * X + y] = val;
+            hess[(size_t)y * X + xr] = val;
+        }
     }
     __syncthreads();
     return energy;
@@ -305,7 +314,8 @@ struct EvalArgs {
     double *energy, *grad, *hess;
 };
 
-__global__ __launch_bounds__(256) void gdml_eval_kernel(EvalArgs A) {
+template <int THREADS, int HN>
+__global__ __launch_bounds__(THREADS, 512 / THREADS) void gdml_eval_kernel(EvalArgs A) {
     extern __shared__ double smem[];
     const int X = 3 * A.G.n_atoms;
     const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train, A.chunk);
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256) void gdml_eval_kernel(EvalArgs A) {
         __syncthreads();
         for (int i = threadIdx.x; i < X; i += blockDim.x) L.pos[i] = A.r[tr * X + i];
         __syncthreads();
-        const double e = gdml_eval_device(A.G, L, A.hess + (size_t)tr * X * X, A.chunk);
+        const double e = gdml_eval_device<HN>(A.G, L, A.hess + (size_t)tr * X * X, A.chunk);
         for (int i = threadIdx.x; i < X; i += blockDim.x) A.grad[tr * X + i] = L.grad[i];
         if (threadIdx.x == 0) A.energy[tr] = e - A.G.origin;
     }
@@ -330,8 +340,8 @@ struct StageArgs {
     double *epart;
 };
 
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
+template <int THREADS, int HN>
+__global__ __launch_bounds__(THREADS, 512 / THREADS) void gdml_stage_kernel(StageArgs A) {
     extern __shared__ double smem[];
     const int D = A.st.dim, tid = threadIdx.x, nth = blockDim.x, s = A.stage;
     const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train, A.chunk);
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
             ps[j] = qp[D + i] + c * kp;
         }
         __syncthreads();
-        const double e = gdml_eval_device(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D, A.chunk) - A.G.origin;
+        const double e = gdml_eval_device<HN>(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D, A.chunk) - A.G.origin;
         double tk[1] = {0.0};
         for (int i = tid, j = 0; i < D; i += nth, ++j) {
             const double im = A.G.inv_mass[i], kq = ps[j] * im, kp = -L.grad[i];
@@ -371,9 +381,19 @@ __global__ __launch_bounds__(THREADS) void gdml_stage_kernel(StageArgs A) {
 
 // training points per staged chunk: the largest of 16, 8, 4 that fits LDS (measured at 30 atoms: a smaller chunk that
 // lets two workgroups share a CU is slower -- more chunk iterations, each with three barriers); the per-wave partial
-// sums (value + compensation term) of the descriptor gradient need chunk >= wavefronts
+}  // namespace
+
+extern "C" int sc_gdml_row_len(int32_t n_atoms) {
+    for (int len : {8, 16, 20, 24, 32})
+        if (n_atoms <= len) return len;
+    return -1;
+}
+
+namespace {
+
 int gdml_chunk(const sc_gdml_model *g, int threads) {
-    const int minc = threads / 64 > 4 ? threads / 64 : 4;
+    (void)threads;
+    const int minc = 4;
     for (int c = GDML_CHUNK_MAX; c >= minc; c /= 2)
         if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, c) * 8 <= 160 * 1024) return c;
     return 0;
@@ -382,10 +402,19 @@ int gdml_chunk(const sc_gdml_model *g, int threads) {
 int check_model(const sc_gdml_model *g, const char *who) {
     if (!g || !g->xs_train || !g->jx_alphas || !g->pair_k || !g->pair_l)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null model field", who);
+    if (!g->xs_sq || !g->a_sq) return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null square-form training arrays", who);
+    if (g->n_atoms > 32) return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms (the square-form rows hold 32)", who, g->n_atoms);
+    if (g->row_len != sc_gdml_row_len(g->n_atoms))
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: row_len %d, %d atoms need %d", who, g->row_len, g->n_atoms, sc_gdml_row_len(g->n_atoms));
     if (g->n_desc != g->n_atoms * (g->n_atoms - 1) / 2)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: descriptor size %d does not match %d atoms", who, g->n_desc, g->n_atoms);
-    if (gdml_chunk(g, 512) == 0)
+    if (gdml_chunk(g, 256) == 0)
         return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d, M=%d) needs more than 160 KiB of LDS", who, g->n_atoms, g->n_train);
+    {
+        const int T = (3 * g->n_atoms + 15) / 16, nw = 4;
+        if (T * (T + 1) / 2 > GDML_MAX_TILES * nw)
+            return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms need more Hessian tiles than the kernel holds", who, g->n_atoms);
+    }
     return SC_OK;
 }
 
@@ -397,13 +426,19 @@ extern "C" int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, 
     if (rc) return rc;
     if (!r || !energy || !grad || !hess) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_eval: null argument");
     if (n <= 0) return SC_OK;
-    const int chunk = gdml_chunk(g, 256);
+    const int chunk = gdml_chunk(g, 256);          // four wavefronts per geometry: two geometries share a CU
     const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, chunk) * 8;
     EvalArgs a{*g, chunk, r, n, energy, grad, hess};
-    if (hipFuncSetAttribute((const void *)gdml_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return sc_check_launch("sc_gdml_eval (LDS attribute)");
     const int grid = (int)(n < 1024 ? n : 1024);
-    hipLaunchKernelGGL(gdml_eval_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+#define SC_GDML_EVAL(HN_)                                                                                                  \
+    case 2 * HN_:                                                                                                          \
+        if (hipFuncSetAttribute((const void *)gdml_eval_kernel<256, HN_>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)lds) != hipSuccess)                                                                   \
+            return sc_check_launch("sc_gdml_eval (LDS attribute)");                                                        \
+        hipLaunchKernelGGL((gdml_eval_kernel<256, HN_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a);              \
+        break;
+    switch (g->row_len) { SC_GDML_EVAL(4) SC_GDML_EVAL(8) SC_GDML_EVAL(10) SC_GDML_EVAL(12) SC_GDML_EVAL(16) }
+#undef SC_GDML_EVAL
     return sc_check_launch("sc_gdml_eval");
 }
 
@@ -419,19 +454,17 @@ extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const s
     if (stage < 0 || stage > 3) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_stage: stage %d", stage);
     if (st->dim > 512) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_stage: D=%d > 512", st->dim);
     if (st->n <= 0) return SC_OK;
-    const bool big = g->n_atoms * (g->n_atoms + 1) / 2 > 256;
-    const int chunk = gdml_chunk(g, big ? 512 : 256);
+    const int chunk = gdml_chunk(g, 256);
     const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, chunk) * 8;
     StageArgs a{*g, chunk, *st, *sc, dt, stage, energy_partials};
-    // big molecules: LDS allows one workgroup per CU anyway, so give a geometry eight wavefronts instead of four
-    if (big) {
-        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return sc_check_launch("sc_gdml_stage (LDS attribute)");
-        hipLaunchKernelGGL(gdml_stage_kernel<512>, dim3(sc_dense_grid(st->n)), dim3(512), lds, (hipStream_t)stream, a);
-    } else {
-        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return sc_check_launch("sc_gdml_stage (LDS attribute)");
-        hipLaunchKernelGGL(gdml_stage_kernel<256>, dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a);
-    }
+#define SC_GDML_STAGE(HN_)                                                                                                 \
+    case 2 * HN_:                                                                                                          \
+        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<256, HN_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                (int)lds) != hipSuccess)                                                                   \
+            return sc_check_launch("sc_gdml_stage (LDS attribute)");                                                       \
+        hipLaunchKernelGGL((gdml_stage_kernel<256, HN_>), dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a); \
+        break;
+    switch (g->row_len) { SC_GDML_STAGE(4) SC_GDML_STAGE(8) SC_GDML_STAGE(10) SC_GDML_STAGE(12) SC_GDML_STAGE(16) }
+#undef SC_GDML_STAGE
     return sc_check_launch("sc_gdml_stage");
 }
