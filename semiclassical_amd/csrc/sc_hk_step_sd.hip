@@ -31,198 +31,9 @@
 //            path is exercised by tests/test_hk_gpu.py::test_weak_pivot_fallback).
 //            Then the sqrt branch tracker.                   (torch.det, propagators.py:999, 1006-1052)
 #include "sc_common.h"
+#include "sc_hk_lu.h"
 
 namespace {
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_mov_i32(int v) {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
-}
-
-__device__ __forceinline__ int row16_max_i32(int v) {
-    asm("s_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_i32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
-        : "+v"(v));
-    return v;
-}
-
-// value of `v` in lane `src` (wave-uniform index) as a wave-uniform scalar
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-
-// 1/z with a hardware reciprocal refined by two Newton steps (full fp64 accuracy for normal |z|^2)
-__device__ __forceinline__ cplx c_inv_fast(cplx z) {
-    const double x = c_abs2(z);
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return c_make(z.x * r, -z.y * r);
-}
-
-struct PivotRecord {        // published by the owner of row k together with the scaled row
-    double re, im;          // pivot value
-    int col, pad;           // pivot column
-};
-
-// Pivot-column entries of the N = NR-KB live row slots from lane pl (wave-uniform, run-time) of every 16-lane DPP
-// row: DPP row_newbcast (no LDS traffic; 64-bit DPP moves exist on gfx90a+ exactly for this control).  The lane is
-// an immediate of the instruction, so there are 16 leaves of 2N moves each and a computed jump (s_setpc_b64) to
-// the leaf of pl; a leaf is 2N*8 + 4 bytes (s_branch to the end).
-#define SC_DPP_MOV(o, i, P) "v_mov_b64_dpp %[" #o "], %[" #i "] row_newbcast:" #P " row_mask:0xf bank_mask:0xf\n\t"
-#define SC_LEAF1(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) "s_branch .Lend_%=\n\t"
-#define SC_LEAF2(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
-    "s_branch .Lend_%=\n\t"
-#define SC_LEAF3(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
-    SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) "s_branch .Lend_%=\n\t"
-#define SC_LEAF4(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
-    SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) SC_DPP_MOV(ox3, ix3, P) SC_DPP_MOV(oy3, iy3, P) "s_branch .Lend_%=\n\t"
-#define SC_LEAVES(L) L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15)
-#define SC_JUMP(BYTES)                                                                           \
-    "s_getpc_b64 vcc\n"                                                                          \
-    ".Lbase_%=:\n\t"                                                                             \
-    "s_mul_i32 %[t], %[pl], " #BYTES "\n\t"                                                      \
-    "s_add_u32 vcc_lo, vcc_lo, %[t]\n\t"                                                         \
-    "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"                                                           \
-    "s_add_u32 vcc_lo, vcc_lo, .Lleaf0_%=-.Lbase_%=\n\t"                                         \
-    "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"                                                           \
-    "s_setpc_b64 vcc\n"                                                                          \
-    ".Lleaf0_%=:\n\t"
-#define SC_IN(n) [ix##n] "v"(m##n.x), [iy##n] "v"(m##n.y)
-#define SC_OUT(n) [ox##n] "=&v"(c##n.x), [oy##n] "=&v"(c##n.y)
-
-__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx &c0) {
-    int t;
-    asm volatile(SC_JUMP(20) SC_LEAVES(SC_LEAF1) ".Lend_%=:\n" : SC_OUT(0), [t] "=&s"(t) : SC_IN(0), [pl] "s"(pl) : "vcc", "scc");
-}
-__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx &c0, cplx &c1) {
-    int t;
-    asm volatile(SC_JUMP(36) SC_LEAVES(SC_LEAF2) ".Lend_%=:\n"
-                 : SC_OUT(0), SC_OUT(1), [t] "=&s"(t) : SC_IN(0), SC_IN(1), [pl] "s"(pl) : "vcc", "scc");
-}
-__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx m2, cplx &c0, cplx &c1, cplx &c2) {
-    int t;
-    asm volatile(SC_JUMP(52) SC_LEAVES(SC_LEAF3) ".Lend_%=:\n"
-                 : SC_OUT(0), SC_OUT(1), SC_OUT(2), [t] "=&s"(t) : SC_IN(0), SC_IN(1), SC_IN(2), [pl] "s"(pl) : "vcc", "scc");
-}
-__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx m2, cplx m3, cplx &c0, cplx &c1, cplx &c2,
-                                               cplx &c3) {
-    int t;
-    asm volatile(SC_JUMP(68) SC_LEAVES(SC_LEAF4) ".Lend_%=:\n"
-                 : SC_OUT(0), SC_OUT(1), SC_OUT(2), SC_OUT(3), [t] "=&s"(t)
-                 : SC_IN(0), SC_IN(1), SC_IN(2), SC_IN(3), [pl] "s"(pl) : "vcc", "scc");
-}
-
-template <int NR, int KB>
-__device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[NR], int pl) {
-    pl = __builtin_amdgcn_readfirstlane(pl);
-    if constexpr (NR - KB == 1) column_fetch_n(pl, m[KB][KB], c[KB]);
-    if constexpr (NR - KB == 2) column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], c[KB], c[KB + 1]);
-    if constexpr (NR - KB == 3) column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], c[KB], c[KB + 1], c[KB + 2]);
-    if constexpr (NR - KB == 4)
-        column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], m[KB + 3][KB], c[KB], c[KB + 1], c[KB + 2], c[KB + 3]);
-}
-
-// The 16 lanes that own row k = 16*KB + kt pick the pivot column among the live columns of the diagonal block,
-// scale the row by 1/pivot and publish it: row -> rowbuf[kt], pivot -> pivrec[kt], and LAST the record's tag
-// (= seq), which the consumers poll.  LDS operations of one wave execute in issue order, so a consumer that sees
-// the tag sees the row.  Runs inside `if (ti == kt)`.
-template <int NR, int KB>
-__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool live, int kt, int seq, cplx (*rowbuf)[64],
-                                                  PivotRecord *pivrec, int *permseq, int *weak) {
-    const int tid = threadIdx.x, tj = tid & 15, lane = tid & 63;
-    const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);       // the matrix row (within the block) this thread holds
-    // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj)
-    const int blk = (__double2hiint(c_abs2(m[KB][KB])) & ~15) | (15 - tj);
-    int key_blk = live ? blk : -1;
-    // every lane inverts its own in-block candidate while the search runs; the winner's is used
-    const cplx myinv = c_inv_fast(m[KB][KB]);
-    key_blk = row16_max_i32(key_blk);
-    const int pl = 15 - (key_blk & 15);
-    const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | pl);
-    const cplx inv = c_make(readlane_f64(myinv.x, src), readlane_f64(myinv.y, src));
-    const bool keep = live && tj != pl;
-    const cplx r0 = c_mul(m[KB][KB], inv);
-    rowbuf[kt][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
-#pragma unroll
-    for (int rb = KB + 1; rb < NR; ++rb) rowbuf[kt][16 * rb + tj] = c_mul(m[KB][rb], inv);
-    if (tj == pl) {                                       // the winner publishes the pivot itself
-        pivrec[kt].re = m[KB][KB].x; pivrec[kt].im = m[KB][KB].y; pivrec[kt].col = 16 * KB + pl;
-        permseq[16 * KB + trow] = 16 * KB + pl;          // row -> pivot column (the sign of this permutation enters c2)
-        __asm__ volatile("" ::: "memory");
-        __hip_atomic_store(&pivrec[kt].pad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __asm__ volatile("" ::: "memory");
-    // |pivot|^2 more than 2^8 below some |a_kj|^2 outside the block: the pivoted fallback redoes the trajectory
-    if (KB + 1 < NR) {
-        int key_out = -1;
-#pragma unroll
-        for (int rb = KB + 1; rb < NR; ++rb) key_out = max(key_out, __double2hiint(c_abs2(m[KB][rb])));
-        if ((key_out & ~15) - (key_blk & ~15) > (8 << 20)) *weak = 1;
-    }
-}
-
-// All elimination steps of the diagonal block KB.  Within block KB only the columns of slot KB are consumed as
-// pivots: `live` (per thread) says whether column (slot KB, lane tj) is still available; slots rb > KB are untouched,
-// slots rb < KB are finished.  Padded columns (j >= D) hold zeros and can never win the magnitude search unless the
-// whole row is zero (= singular: flagged, the arithmetic runs on with inf/nan and the result is discarded).
-// No barrier inside the block: the four waves run the 16 steps as a dataflow pipeline.  A wave waits for row kt by
-// polling the tag of pivrec[kt] (reading the record and the row in the same batch), fetches the pivot-column entries
-// with DPP, updates row slot KB first so that the 16 lanes owning row kt+1 can search and publish at once, and only
-// then does the rest of its rank-1 update.  The chain owner(kt) -> owner(kt+1) is the critical path; the bulk of
-// the update floats beside it.  One barrier per block protects the reuse of the 16 row buffers.
-// The pivot ORDER inside a block is kt = 0..15 with thread index ti = 4 j + w (j = 16-lane row of the wave, w = wave):
-// consecutive pivots are owned by different waves.  The matrix ROW a thread holds is trow = 4 w + j (a wave streams
-// four consecutive rows, see the kernel), i.e. pivot step kt eliminates row 4 (kt & 3) + (kt >> 2) of the block; steps
-// whose row lies beyond D are skipped.  The order in which rows are eliminated does not change the determinant.
-__device__ __forceinline__ bool pivot_step_valid(int kt, int nk) { return 4 * (kt & 3) + (kt >> 2) < nk; }
-
-template <int NR, int KB>
-__device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bool &singular, int D, int seq,
-                                                cplx (*rowbuf)[64], PivotRecord *pivrec, int *permseq, int *weak) {
-    const int tid = threadIdx.x, ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;
-    const int nk = min(16, D - 16 * KB);
-    bool live = 16 * KB + tj < D;
-    __syncthreads();
-    if (ti == 0) publish_pivot_row<NR, KB>(m, live, 0, seq, rowbuf, pivrec, permseq, weak);
-    for (int kt = 0; kt < 16; ++kt) {
-        if (!pivot_step_valid(kt, nk)) continue;
-        int next = kt + 1;
-        while (next < 16 && !pivot_step_valid(next, nk)) ++next;
-        double re, im;
-        int col;
-        cplx r[NR];
-        for (;;) {
-            const int tag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pivrec[kt].pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            __asm__ volatile("" ::: "memory");
-            re = pivrec[kt].re; im = pivrec[kt].im; col = pivrec[kt].col;
-#pragma unroll
-            for (int rb = KB; rb < NR; ++rb) r[rb] = rowbuf[kt][16 * rb + tj];
-            __asm__ volatile("" ::: "memory");
-            if (tag == seq) break;
-        }
-        singular = singular || (re == 0.0 && im == 0.0);
-        if (tid < 64) det = c_mul(det, c_make(re, im));
-        const int pl = col & 15;
-        live = live && tj != pl;
-        cplx c[NR];
-        column_fetch<NR, KB>(m, c, pl);
-        if (ti <= kt) c[KB] = c_make(0.0, 0.0);
-#pragma unroll
-        for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
-        if (next < 16 && ti == next) publish_pivot_row<NR, KB>(m, live, next, seq, rowbuf, pivrec, permseq, weak);
-#pragma unroll
-        for (int ra = KB + 1; ra < NR; ++ra) {
-#pragma unroll
-            for (int rb = KB; rb < NR; ++rb) m[ra][rb] = c_fnma(c[ra], r[rb], m[ra][rb]);
-        }
-    }
-}
 
 // TILED: the monodromy blocks of a trajectory are stored as 16 x 16 tiles (sc_state.mono_layout = 1, see the header):
 // tile (ra, rb) holds its part of Mqq, Mqp, Mpq, Mpp one after the other, each row-major inside the tile.  With the
@@ -333,10 +144,11 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         constexpr bool skip_lu = false;
 #endif
         if (!skip_lu) {
-            eliminate_block<NR, 0>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, &weak);
-            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, &weak);
-            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, &weak);
-            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, &weak);
+            auto wg_barrier = [] { __syncthreads(); };
+            eliminate_block<NR, 0>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
         }
         __syncthreads();
         if (tid == 0 && weak && A.st.flags && !skip_lu) {
@@ -573,6 +385,10 @@ __global__ __launch_bounds__(256) void hk_step_w16_kernel(StepArgs A) {
 
 }  // namespace
 
+#ifdef SC_TUNING
+int sc_launch_step_ws(const StepArgs &a, hipStream_t s);       // tools/variants/sc_hk_step_ws.hip (measured, not adopted)
+#endif
+
 // launch the fast path; the caller has validated the arguments (separable potential, diag prefactor, D <= 64)
 int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     const int D = a.st.dim, nr = (D + 15) / 16, grid = sc_step_grid(a.st.n, D);
@@ -595,6 +411,12 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     if ((a.mode & 0xff) == 0) hipLaunchKernelGGL(hk_modes_kernel, dim3(grid), dim3(256), 0, s, a);
     const bool step = (a.mode & 0xff) == 0;
     const bool tiled = a.st.mono_layout == SC_MONO_TILED16;
+#ifdef SC_TUNING
+    // SC_WS=1: the wave-specialised schedule (one producer + three eliminator groups per CU).  Measured on MI355X at
+    // n = 1e5, D = 60: 6.71 ms against 5.98 ms of this kernel -- the eliminations are bound by VALU issue, not by their
+    // latency, so giving them a CU of their own does not help.
+    if (nr == 4 && step && a.mode == 0 && getenv("SC_WS")) return sc_launch_step_ws(a, s);
+#endif
 #define SC_LAUNCH_SD(NR_, OCC_)                                                                                         \
     do {                                                                                                                \
         if (step && tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, true>), dim3(grid), dim3(256), 0, s, a);   \
