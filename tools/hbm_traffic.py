@@ -49,9 +49,11 @@ def main():
     n, dim = 100000, 60
     fetch = per_kernel(fetch_dir, "FETCH_SIZE")
     write = per_kernel(write_dir, "WRITE_SIZE")
-    kstep, f_step = pick(fetch, "hk_step_sd_kernel", "true")
-    _, f_pref = pick(fetch, "hk_step_sd_kernel", "false")
-    _, w_step = pick(write, "hk_step_sd_kernel", "true")
+    # template arguments <NR, MINW, STEP, TILED>: the step launches run on the tiled layout, the prefactor-only launch
+    # of initial_conditions() on the row-major one
+    kstep, f_step = pick(fetch, "hk_step_sd_kernel", "true, true>")
+    _, f_pref = pick(fetch, "hk_step_sd_kernel", "false, false>")
+    _, w_step = pick(write, "hk_step_sd_kernel", "true, true>")
     _, f_modes = pick(fetch, "hk_modes_kernel")
     _, w_modes = pick(write, "hk_modes_kernel")
     mean = lambda x: sum(x) / len(x)
