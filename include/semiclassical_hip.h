@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        6
+#define SC_ABI_VERSION        7
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -274,10 +274,13 @@ int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const sc_dense_scr
                   double *energy_partials, void *stream);
 
 /* RK4 of the four monodromy blocks with the four stage Hessians hess[n][4][D][D] (each used as A[i][k] = hess[k][i];
- * the built-in potentials produce symmetric images) on the FP64 matrix cores, then the HK prefactor (diagonal or
- * dense/rank-deficient width matrices) and its branch tracking; D <= 96.  For D > 64 the RK4 sums do not fit the
- * register file: mono_sums [n][4][D][D] is their scratch (may be NULL for D <= 64).  mode: 0 = step + prefactor,
- * 1 = prefactor and tracker initialisation only. */
+ * the built-in potentials produce symmetric images), then the HK prefactor (diagonal or dense/rank-deficient width
+ * matrices) and its branch tracking.  D <= 96: on the FP64 matrix cores; for 64 < D the RK4 sums do not fit the
+ * register file and live in `mono_sums`.  D > 96: no size limit -- every matrix of a trajectory in a per-workgroup block
+ * of `mono_sums`, products on the vector ALUs, pivoted LU on global memory (slow, kept for parity with the unbounded
+ * reference).  `mono_sums`: sc_dense_mono_scratch_bytes(n, D, d') bytes (0: may be NULL).
+ * mode: 0 = step + prefactor, 1 = prefactor and tracker initialisation only. */
+int64_t sc_dense_mono_scratch_bytes(int64_t n, int32_t D, int32_t dprime);
 int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
                        double *mono_sums, double dt, int32_t mode, void *stream);
 

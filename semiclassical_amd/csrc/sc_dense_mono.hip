@@ -366,19 +366,24 @@ extern "C" int sc_stage_consume(const sc_state *st, const sc_dense_scratch *sc, 
     return sc_check_launch("sc_stage_consume");
 }
 
+int sc_launch_dense_any(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
+                        double *scratch, double dt, int mode, hipStream_t s);        // sc_dense_any.hip
+
 extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, const double *inv_mass, const double *hess,
                                   double *mono_sums, double dt, int32_t mode, void *stream) {
     if (!st || !hk || (mode == 0 && (!inv_mass || !hess)))
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: null argument");
     const int D = st->dim;
     if (int rq = sc_require_rowmajor(st, "sc_dense_mono_step")) return rq;
-    if (D < 1 || D > 96) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: D=%d outside 1..96", D);
-    if (D > 64 && mode == 0 && !mono_sums)
-        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: D=%d > 64 needs the mono_sums scratch", D);
+    if (D < 1) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: D=%d", D);
+    if (D > 64 && (mode == 0 || D > 96) && !mono_sums)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: D=%d > 64 needs the mono_sums scratch "
+                       "(sc_dense_mono_scratch_bytes)", D);
     if (hk->dim != D || hk->dprime < 1 || hk->dprime > D)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_dense_mono_step: bad prefactor constants");
     if (st->n <= 0) return SC_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (D > 96) return sc_launch_dense_any(st, hk, inv_mass, hess, mono_sums, dt, mode, s);    // no size limit, slow
     // prefactor kernel: d' x d' matrix + a panel of X = M R in LDS
     const size_t dp = hk->dprime, budget = 150 * 1024;
     int panel = (int)dp;

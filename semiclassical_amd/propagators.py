@@ -200,7 +200,7 @@ class HermanKlukPropagator(object):
     def _prefactor_initial(self):
         """prefactor at t = 0 and initialisation of the branch tracker (reference propagators.py:631)"""
         if self.dim > 64:
-            check(lib.sc_dense_mono_step(self._state, self._hk, None, None, None, 0.0, 1, self._stream()))
+            check(lib.sc_dense_mono_step(self._state, self._hk, None, None, self._mono_sums_ptr(), 0.0, 1, self._stream()))
         else:
             check(lib.sc_hk_step(_NULL_POT(self.dim), self._state, self._hk, 0.0, 1, None, self._stream()))
         self._after_prefactor(track=2)
@@ -318,11 +318,14 @@ class HermanKlukPropagator(object):
         return self._dense
 
     def _mono_sums_ptr(self):
-        """scratch for the RK4 sums of the monodromy blocks, only needed beyond D = 64 (sc_dense_mono_step)"""
-        if self.dim <= 64:
+        """scratch of sc_dense_mono_step beyond D = 64: the RK4 sums of the MFMA kernel up to D = 96, the per-workgroup
+        matrix blocks of the any-dimension kernels beyond (sc_dense_mono_scratch_bytes)"""
+        need = lib.sc_dense_mono_scratch_bytes(self.ntraj, self.dim, self._hk.dprime)
+        assert need >= 0
+        if need == 0:
             return None
-        if getattr(self, "_mono_sums", None) is None or self._mono_sums.shape != self._mono.shape:
-            self._mono_sums = torch.empty_like(self._mono)
+        if getattr(self, "_mono_sums", None) is None or self._mono_sums.numel() * 8 < need:
+            self._mono_sums = torch.empty((need + 7) // 8, dtype=F64, device=self.device)
         return ptr(self._mono_sums)
 
     def _launch_generic_step(self, potential, dt, s):

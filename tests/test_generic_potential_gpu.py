@@ -77,15 +77,16 @@ def test_generic_python_potential_matches_oracle(kind):
     assert cases.rel_err(prop.y.cpu().numpy(), y_ref) < 1e-9
 
 
-@pytest.mark.parametrize("dense_gamma", [False, True])
-def test_more_than_64_dimensions_through_the_dense_path(dense_gamma):
-    """D = 70 > 64: beyond the fused kernels every potential takes the dense path (its own torch code at the stage
-    points, MFMA monodromy kernel for 64 < D <= 96 with the RK4 sums in a global scratch, panelised prefactor);
-    anharmonic AS (Morse) model with diagonal or rotated width matrices against the CPU oracle"""
+@pytest.mark.parametrize("D,dense_gamma", [(70, False), (70, True), (100, False), (100, True), (130, True)])
+def test_more_than_64_dimensions_through_the_dense_path(D, dense_gamma):
+    """Beyond the fused kernels (D > 64) every potential takes the dense path (its own torch code at the stage points):
+    MFMA monodromy kernel with the RK4 sums in a global scratch and a panelised prefactor up to D = 96, the
+    any-dimension kernels (global scratch, pivoted LU on global memory) beyond -- the reference has no size limit
+    (propagators.py:313-383).  Anharmonic AS (Morse) model, diagonal or rotated width matrices, against the CPU oracle."""
     from oracle import sc_oracle as orc
     from semiclassical_amd import potentials as P, propagators as PR
-    rng = np.random.default_rng(70)
-    D, n, nt, dt = 70, 24, 4, 2.0
+    rng = np.random.default_rng(D)
+    n, nt, dt = (24, 4, 2.0) if D <= 96 else (10, 3, 2.0)
     omega = torch.from_numpy(np.sort(rng.uniform(400, 3200, D)) / 219474.63)
     S = torch.from_numpy(rng.uniform(0.01, 0.1, D) * rng.choice([-1, 1], D))
     nac = torch.from_numpy(rng.normal(0, 1e-4, D))

@@ -231,8 +231,9 @@ def test_unsupported_sizes_fail_loudly():
                              None, None))
     with pytest.raises(EngineError, match="null argument"):
         check(lib.sc_hk_step(None, None, None, 0.1, 0, None, None))
-    # beyond the dense path's D <= 96
-    with pytest.raises(EngineError, match="outside 1..96"):
+    # beyond D = 96 the dense path needs its scratch block
+    assert lib.sc_dense_mono_scratch_bytes(10, 100, 100) > 0 and lib.sc_dense_mono_scratch_bytes(10, 64, 64) == 0
+    with pytest.raises(EngineError, match="mono_sums scratch"):
         check(lib.sc_dense_mono_step(sc_state(n=1, dim=100), sc_hk_consts(dim=100, dprime=100, diag=1), None, None, None,
                                      0.0, 1, None))
 
