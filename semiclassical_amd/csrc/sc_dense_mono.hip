@@ -250,6 +250,115 @@ __global__ __launch_bounds__(64 * NT, 1) void dense_mono_mfma_big_kernel(MonoArg
     }
 }
 
+// 64 < D <= 96 with the whole RK4 step in registers (round 2; replaces the global-scratch kernel above as the default).
+// The equations of motion couple the ROWS of a monodromy block through H but not its columns: a 16-column tile of
+// X = [Mqq|Mqp] together with the same tile of Y = [Mpq|Mpp] is an independent problem.  So a trajectory is cut into
+// slabs of four column tiles; a 256-thread workgroup takes one slab, every wavefront one tile for ALL rows, and keeps
+// X0, Y0, the stage matrices and the RK4 sums of its tile in registers (24 NT doubles + accumulators: the kernel is
+// compiled for one wave per SIMD = 512 registers).  No scratch traffic at all: per trajectory the state is read and
+// written once (2 x 4 D^2 x 8 B) and the four stage Hessians are read once per slab (2 NT / 4 slabs), against ~3 MB
+// through the global scratch of dense_mono_mfma_big_kernel.  One Hessian image in LDS (rows padded to 112 doubles); the
+// next stage's image is fetched into registers behind the current stage's MFMAs.
+template <int NT, int KT>
+__global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A) {
+    extern __shared__ double2 smem2[];           // Hessian image [16 NT][HSB], 1/m [128]
+    constexpr int HB = 16 * NT * HSB, NSLAB = (2 * NT + 3) / 4;
+    constexpr int HPT = (16 * NT * 16 * NT + 255) / 256;      // Hessian elements fetched per thread
+    double *Hs0 = (double *)smem2, *wm = Hs0 + HB;
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, rg = lane >> 4;
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    for (int i = tid; i < 128; i += 256) wm[i] = i < D ? A.inv_mass[i] : 0.0;
+    for (int e = tid; e < HB; e += 256) Hs0[e] = 0.0;                        // padding rows / columns stay zero
+    __syncthreads();
+    const int64_t items = A.st.n * NSLAB;
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t tr = item / NSLAB;
+        const int ct = 4 * (int)(item - tr * NSLAB) + wave;                  // column tile of [X | X'] this wavefront owns
+        const bool active = ct < 2 * NT;
+        const int pair = active ? ct / NT : 0, jt = active ? ct % NT : 0;    // pair 0: (Mqq, Mpq), pair 1: (Mqp, Mpp)
+        const int col = 16 * jt + (lane & 15);
+        const bool colok = active && col < D;
+        const unsigned toff = (unsigned)(rg * D + col);
+        double *Mx = A.st.mono + tr * 4 * (int64_t)DD + (int64_t)pair * DD, *My = Mx + 2 * (int64_t)DD;
+        const double *Hg = A.hess + tr * A.hess_stride;
+        __syncthreads();                                                     // the previous item's last image is done with
+        for (int e = tid; e < DD; e += 256) Hs0[(e / D) * HSB + (e % D)] = Hg[e];
+        double SX[NT][4], SY[NT][4], Xs[NT][4], Ys[NT][4], X0[NT][4], Y0[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = colok && 16 * t + rg + 4 * r < D;
+                X0[t][r] = Xs[t][r] = ok ? (Mx + (16 * t + 4 * r) * D)[toff] : 0.0;
+                Y0[t][r] = Ys[t][r] = ok ? (My + (16 * t + 4 * r) * D)[toff] : 0.0;
+                SX[t][r] = 0.0; SY[t][r] = 0.0;
+            }
+#pragma unroll 1
+        for (int st = 0; st < 4; ++st) {
+            __syncthreads();                                                 // image of this stage complete
+            double hn[HPT];
+            const double *Hn = Hg + (st + 1) * A.stage_stride;
+            if (st < 3) {
+#pragma unroll
+                for (int i = 0; i < HPT; ++i) {
+                    const int e = tid + i * 256;
+                    hn[i] = e < DD ? Hn[e] : 0.0;
+                }
+            }
+            d4 acc[NT];
+#pragma unroll
+            for (int I = 0; I < NT; ++I) acc[I] = (d4){0.0, 0.0, 0.0, 0.0};
+            const double *arow = Hs0 + rg * HSB + (lane & 15);
+            double a_cur[NT], a_nxt[NT];
+#pragma unroll
+            for (int I = 0; I < NT; ++I) a_cur[I] = arow[16 * I];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt + 1 < KT) {
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) a_nxt[I] = arow[4 * (kt + 1) * HSB + 16 * I];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double b = Xs[kt >> 2][kt & 3];
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[I], b, acc[I], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int I = 0; I < NT; ++I) a_cur[I] = a_nxt[I];
+            }
+            const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double kx = wm[16 * t + rg + 4 * r] * Ys[t][r], ky = -acc[t][r];
+                    SX[t][r] = fma(wgt, kx, SX[t][r]); SY[t][r] = fma(wgt, ky, SY[t][r]);
+                    Xs[t][r] = fma(c, kx, X0[t][r]);
+                    Ys[t][r] = fma(c, ky, Y0[t][r]);
+                }
+            if (st < 3) {
+                __syncthreads();                                             // everybody has read this stage's image
+#pragma unroll
+                for (int i = 0; i < HPT; ++i) {
+                    const int e = tid + i * 256;
+                    if (e < DD) Hs0[(e / D) * HSB + (e % D)] = hn[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (colok && 16 * t + rg + 4 * r < D) {
+                    (Mx + (16 * t + 4 * r) * D)[toff] = fma(h6, SX[t][r], X0[t][r]);
+                    (My + (16 * t + 4 * r) * D)[toff] = fma(h6, SY[t][r], Y0[t][r]);
+                }
+            }
+    }
+}
+
 // prefactor matrix, determinant and branch tracker from the monodromy blocks in global memory
 __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
     extern __shared__ double2 smem2[];
@@ -397,6 +506,10 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
         const int nt = (D + 15) / 16;
+        bool use_big = false;                     // the global-scratch kernel: kept for A/B in the tuning build
+#ifdef SC_TUNING
+        use_big = nt > 4 && getenv("SC_MONO_BIG") != nullptr;
+#endif
         const size_t rk4_lds = nt <= 4 ? ((size_t)2 * 16 * nt * HS + 64 + (size_t)2 * nt * (nt < 4 ? 2 : 1) * 4 * nt * 64) * sizeof(double)
                                        : ((size_t)16 * nt * HSB + 128) * sizeof(double);
 #define SC_LAUNCH_MONO(KERNEL_, NT_, KT_, WGS_, THREADS_)                                                          \
@@ -404,8 +517,8 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
             if (hipFuncSetAttribute((const void *)KERNEL_<NT_, KT_>,                                                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)rk4_lds) != hipSuccess)        \
                 return sc_check_launch("sc_dense_mono_step (LDS attribute)");                                       \
-            const int64_t g_ = (int64_t)cus * (WGS_);                                                               \
-            hipLaunchKernelGGL((KERNEL_<NT_, KT_>), dim3((unsigned)(st->n < g_ ? st->n : g_)),                      \
+            const int64_t g_ = (int64_t)cus * (WGS_), items_ = st->n * (nt > 4 && !use_big ? (2 * nt + 3) / 4 : 1); \
+            hipLaunchKernelGGL((KERNEL_<NT_, KT_>), dim3((unsigned)(items_ < g_ ? items_ : g_)),                    \
                                dim3(THREADS_), rk4_lds, s, a);                                                      \
         } while (0)
 #define SC_MONO_CASES(KERNEL_, NT_, WGS_, THREADS_)                                                                 \
@@ -413,13 +526,20 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
         case 4 * NT_ - 2: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_ - 2, WGS_, THREADS_); break;                         \
         case 4 * NT_ - 1: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_ - 1, WGS_, THREADS_); break;                         \
         case 4 * NT_: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_, WGS_, THREADS_); break;
-        switch ((D + 3) / 4) {
-            SC_MONO_CASES(dense_mono_mfma_kernel, 1, 8, 128)
-            SC_MONO_CASES(dense_mono_mfma_kernel, 2, 4, 256)
-            SC_MONO_CASES(dense_mono_mfma_kernel, 3, 1, 384)
-            SC_MONO_CASES(dense_mono_mfma_kernel, 4, 1, 512)
-            SC_MONO_CASES(dense_mono_mfma_big_kernel, 5, 1, 320)
-            SC_MONO_CASES(dense_mono_mfma_big_kernel, 6, 1, 384)
+        if (use_big) {
+            switch ((D + 3) / 4) {
+                SC_MONO_CASES(dense_mono_mfma_big_kernel, 5, 1, 320)
+                SC_MONO_CASES(dense_mono_mfma_big_kernel, 6, 1, 384)
+            }
+        } else {
+            switch ((D + 3) / 4) {
+                SC_MONO_CASES(dense_mono_mfma_kernel, 1, 8, 128)
+                SC_MONO_CASES(dense_mono_mfma_kernel, 2, 4, 256)
+                SC_MONO_CASES(dense_mono_mfma_kernel, 3, 1, 384)
+                SC_MONO_CASES(dense_mono_mfma_kernel, 4, 1, 512)
+                SC_MONO_CASES(dense_mono_mfma_slab_kernel, 5, 4, 256)
+                SC_MONO_CASES(dense_mono_mfma_slab_kernel, 6, 4, 256)
+            }
         }
 #undef SC_MONO_CASES
 #undef SC_LAUNCH_MONO
