@@ -19,6 +19,7 @@
 // by pivoted LU in LDS, followed by the branch tracker (propagators.py:951-1052).
 #include "sc_common.h"
 #include "sc_prefactor.h"
+#include "sc_hk_lu.h"
 
 namespace {
 
@@ -33,6 +34,7 @@ struct MonoArgs {
     int panel;                  // columns of M R formed at a time in the prefactor kernel (LDS budget)
     double dt;
     int mode;                   // 0: after a step, 1: tracker initialisation (prefactor kernel only)
+    int fixup;                  // LDS prefactor kernel: only the trajectories the register kernel flagged (weak pivots)
 };
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -365,7 +367,9 @@ __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
     __shared__ int ipiv;
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x, nth = blockDim.x, dp = A.hk.dprime;
     cplx *mat = (cplx *)smem2, *X = mat + (size_t)dp * dp;
+    if (A.fixup && A.st.flags[A.st.n] == 0) return;          // nothing was flagged in this step
     for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+        if (A.fixup && A.st.flags[tr] == 0) continue;        // uniform over the workgroup
         const double *M = A.st.mono + tr * 4 * (int64_t)DD;
         __syncthreads();
         if (A.hk.diag) {
@@ -389,7 +393,94 @@ __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
                 A.st.sgn[tr] = 1.0;
             }
             c2[tr] = det;
+            if (A.fixup) A.st.flags[tr] = 0;
         }
+    }
+}
+
+// The same determinant with the matrix in REGISTERS for diagonal width matrices and D <= 96 (round 2): the block-pivoted
+// dataflow elimination of the separable fast path (sc_hk_lu.h) with NR = ceil(D/16) <= 6 row / column slots per thread.
+// The LDS kernel above needs 16 d'^2 bytes per trajectory (one workgroup per CU at D = 90) and two barriers per pivot:
+// 10 ms at D = 90, n = 1e4.  Trajectories whose in-block pivot is too weak are flagged and redone by the LDS kernel.
+template <int NR, int KB, int RW, class Barrier>
+__device__ __forceinline__ void eliminate_all_blocks(cplx (&m)[NR][NR], cplx &det, bool &singular, int D, int seq0, cplx (*rowbuf)[RW],
+                                                     PivotRecord *pivrec, int *permseq, int *weak, int tid, Barrier &&barrier) {
+    if constexpr (KB < NR) {
+        eliminate_block<NR, KB, RW>(m, det, singular, D, seq0 + 1 + KB, rowbuf, pivrec, permseq, weak, tid, barrier);
+        eliminate_all_blocks<NR, KB + 1, RW>(m, det, singular, D, seq0, rowbuf, pivrec, permseq, weak, tid, barrier);
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kernel(MonoArgs A) {
+    constexpr int RW = 16 * NR;
+    __shared__ cplx rowbuf[16][RW];
+    __shared__ PivotRecord pivrec[16];
+    __shared__ int permseq[RW];
+    __shared__ int weak;
+    __shared__ double scl[4 * RW];           // st, 1/st, si, 1/si
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x, tj = tid & 15;
+    const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);
+    if (tid < 16) pivrec[tid].pad = 0;
+    if (tid < RW) {
+        const double st = tid < D ? A.hk.st[tid] : 1.0, si = tid < D ? A.hk.si[tid] : 1.0;
+        scl[tid] = st; scl[RW + tid] = 1.0 / st; scl[2 * RW + tid] = si; scl[3 * RW + tid] = 1.0 / si;
+    }
+    __syncthreads();
+    auto barrier = [] { __syncthreads(); };
+    const unsigned to = (unsigned)(trow * D + tj);
+    int seq0 = 0;
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += NR) {
+        const double *M = A.st.mono + tr * 4 * (int64_t)DD;
+        if (tid == 0) weak = 0;
+        int til = trow, tjl = tj;
+        __asm__ volatile("" : "+v"(til), "+v"(tjl));            // LDS indices recomputed per trajectory, not hoisted and spilled
+        cplx m[NR][NR];
+#pragma unroll
+        for (int ra = 0; ra < NR; ++ra) {
+            const int a = 16 * ra + til;
+            const double sa = scl[a], isa = scl[RW + a];
+            double v[4][NR];
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) {
+                const bool ok = a < D && 16 * rb + tj < D;
+                const double *pe = M + __builtin_amdgcn_readfirstlane(16 * ra * D + 16 * rb);     // wave-uniform base + one 32-bit offset
+                v[0][rb] = ok ? pe[to] : 0.0; v[1][rb] = ok ? pe[DD + to] : 0.0;
+                v[2][rb] = ok ? pe[2 * DD + to] : 0.0; v[3][rb] = ok ? pe[3 * DD + to] : 0.0;
+            }
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) {
+                const int b = 16 * rb + tjl;
+                const double sb = scl[2 * RW + b], isb = scl[3 * RW + b];
+                m[ra][rb] = c_make(0.5 * (sa * isb * v[0][rb] + isa * sb * v[3][rb]),
+                                   0.5 * (-SC_HBAR * sa * sb * v[1][rb] + (1.0 / SC_HBAR) * isa * isb * v[2][rb]));
+                // the element must exist before the next slot's loads are issued: otherwise every raw value of the
+                // trajectory (4 NR^2 doubles) is loaded first and spilled
+                __asm__ volatile("" : "+v"(m[ra][rb].x), "+v"(m[ra][rb].y) : : "memory");
+            }
+        }
+        cplx det = c_make(1.0, 0.0);
+        bool singular = false;
+        eliminate_all_blocks<NR, 0, RW>(m, det, singular, D, seq0, rowbuf, pivrec, permseq, &weak, tid, barrier);
+        __syncthreads();
+        if (tid == 0) {
+            if (weak) {
+                A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted LDS elimination
+                atomicAdd(&A.st.flags[A.st.n], 1);
+            } else {
+                if (singular) det = c_make(0.0, 0.0);
+                else if (permutation_is_odd(permseq, D)) det = c_make(-det.x, -det.y);
+                cplx *c2 = (cplx *)A.st.c2;
+                if (A.mode == 0) {
+                    const cplx prev = c2[tr];
+                    if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
+                } else {
+                    A.st.sgn[tr] = 1.0;
+                }
+                c2[tr] = det;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -499,7 +590,7 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
     if (!hk->diag) while (panel > 8 && (dp * dp + (size_t)D * panel) * 16 + 32 > budget) panel = (panel + 1) / 2;
     const size_t lds = (dp * dp + (hk->diag ? 0 : (size_t)D * panel)) * 16 + 32;
     if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_dense_mono_step: needs %zu B of LDS", lds);
-    MonoArgs a{*st, *hk, inv_mass, hess, 4 * (int64_t)D * D, (int64_t)D * D, mono_sums, panel, dt, mode};
+    MonoArgs a{*st, *hk, inv_mass, hess, 4 * (int64_t)D * D, (int64_t)D * D, mono_sums, panel, dt, mode, 0};
     if (mode == 0) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -545,6 +636,27 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
 #undef SC_LAUNCH_MONO
         const int rc = sc_check_launch("sc_dense_mono_step (RK4)");
         if (rc) return rc;
+    }
+    bool reg_lu = hk->diag && st->flags != nullptr;       // diagonal widths: determinant in registers, LDS kernel as the fix-up
+#ifdef SC_TUNING
+    if (getenv("SC_PREFACTOR_LDS")) reg_lu = false;
+#endif
+    if (reg_lu) {
+        if (hipMemsetAsync(st->flags + st->n, 0, sizeof(int32_t), s) != hipSuccess)
+            return sc_check_launch("sc_dense_mono_step (flag counter)");
+        const int64_t cap = 1024;
+        const unsigned grid = (unsigned)(st->n < cap ? st->n : cap);
+        switch ((D + 15) / 16) {
+            case 1: hipLaunchKernelGGL(dense_prefactor_reg_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL(dense_prefactor_reg_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
+            case 3: hipLaunchKernelGGL(dense_prefactor_reg_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL(dense_prefactor_reg_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+            case 5: hipLaunchKernelGGL(dense_prefactor_reg_kernel<5>, dim3(grid), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL(dense_prefactor_reg_kernel<6>, dim3(grid), dim3(256), 0, s, a); break;
+        }
+        const int rc = sc_check_launch("sc_dense_mono_step (register prefactor)");
+        if (rc) return rc;
+        a.fixup = 1;
     }
     if (hipFuncSetAttribute((const void *)dense_prefactor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return sc_check_launch("sc_dense_mono_step (LDS attribute)");

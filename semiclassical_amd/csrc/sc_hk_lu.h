@@ -55,6 +55,12 @@ struct PivotRecord {        // published by the owner of row k together with the
     SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) "s_branch .Lend_%=\n\t"
 #define SC_LEAF4(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
     SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) SC_DPP_MOV(ox3, ix3, P) SC_DPP_MOV(oy3, iy3, P) "s_branch .Lend_%=\n\t"
+#define SC_LEAF5(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
+    SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) SC_DPP_MOV(ox3, ix3, P) SC_DPP_MOV(oy3, iy3, P)              \
+    SC_DPP_MOV(ox4, ix4, P) SC_DPP_MOV(oy4, iy4, P) "s_branch .Lend_%=\n\t"
+#define SC_LEAF6(P) SC_DPP_MOV(ox0, ix0, P) SC_DPP_MOV(oy0, iy0, P) SC_DPP_MOV(ox1, ix1, P) SC_DPP_MOV(oy1, iy1, P) \
+    SC_DPP_MOV(ox2, ix2, P) SC_DPP_MOV(oy2, iy2, P) SC_DPP_MOV(ox3, ix3, P) SC_DPP_MOV(oy3, iy3, P)              \
+    SC_DPP_MOV(ox4, ix4, P) SC_DPP_MOV(oy4, iy4, P) SC_DPP_MOV(ox5, ix5, P) SC_DPP_MOV(oy5, iy5, P) "s_branch .Lend_%=\n\t"
 #define SC_LEAVES(L) L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15)
 #define SC_JUMP(BYTES)                                                                           \
     "s_getpc_b64 vcc\n"                                                                          \
@@ -91,6 +97,21 @@ __device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx m2
                  : SC_IN(0), SC_IN(1), SC_IN(2), SC_IN(3), [pl] "s"(pl) : "vcc", "scc");
 }
 
+__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx m2, cplx m3, cplx m4, cplx &c0, cplx &c1, cplx &c2,
+                                               cplx &c3, cplx &c4) {
+    int t;
+    asm volatile(SC_JUMP(84) SC_LEAVES(SC_LEAF5) ".Lend_%=:\n"
+                 : SC_OUT(0), SC_OUT(1), SC_OUT(2), SC_OUT(3), SC_OUT(4), [t] "=&s"(t)
+                 : SC_IN(0), SC_IN(1), SC_IN(2), SC_IN(3), SC_IN(4), [pl] "s"(pl) : "vcc", "scc");
+}
+__device__ __forceinline__ void column_fetch_n(int pl, cplx m0, cplx m1, cplx m2, cplx m3, cplx m4, cplx m5, cplx &c0, cplx &c1,
+                                               cplx &c2, cplx &c3, cplx &c4, cplx &c5) {
+    int t;
+    asm volatile(SC_JUMP(100) SC_LEAVES(SC_LEAF6) ".Lend_%=:\n"
+                 : SC_OUT(0), SC_OUT(1), SC_OUT(2), SC_OUT(3), SC_OUT(4), SC_OUT(5), [t] "=&s"(t)
+                 : SC_IN(0), SC_IN(1), SC_IN(2), SC_IN(3), SC_IN(4), SC_IN(5), [pl] "s"(pl) : "vcc", "scc");
+}
+
 template <int NR, int KB>
 __device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[NR], int pl) {
     pl = __builtin_amdgcn_readfirstlane(pl);
@@ -99,14 +120,20 @@ __device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[
     if constexpr (NR - KB == 3) column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], c[KB], c[KB + 1], c[KB + 2]);
     if constexpr (NR - KB == 4)
         column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], m[KB + 3][KB], c[KB], c[KB + 1], c[KB + 2], c[KB + 3]);
+    if constexpr (NR - KB == 5)
+        column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], m[KB + 3][KB], m[KB + 4][KB], c[KB], c[KB + 1], c[KB + 2],
+                       c[KB + 3], c[KB + 4]);
+    if constexpr (NR - KB == 6)
+        column_fetch_n(pl, m[KB][KB], m[KB + 1][KB], m[KB + 2][KB], m[KB + 3][KB], m[KB + 4][KB], m[KB + 5][KB], c[KB], c[KB + 1],
+                       c[KB + 2], c[KB + 3], c[KB + 4], c[KB + 5]);
 }
 
 // The 16 lanes that own row k = 16*KB + kt pick the pivot column among the live columns of the diagonal block,
 // scale the row by 1/pivot and publish it: row -> rowbuf[kt], pivot -> pivrec[kt], and LAST the record's tag
 // (= seq), which the consumers poll.  LDS operations of one wave execute in issue order, so a consumer that sees
 // the tag sees the row.  Runs inside `if (ti == kt)`.
-template <int NR, int KB>
-__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool live, int kt, int seq, cplx (*rowbuf)[64],
+template <int NR, int KB, int RW>
+__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool live, int kt, int seq, cplx (*rowbuf)[RW],
                                                   PivotRecord *pivrec, int *permseq, int *weak, int tid) {
     const int tj = tid & 15, lane = tid & 63;
     const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);       // the matrix row (within the block) this thread holds
@@ -157,15 +184,15 @@ __device__ __forceinline__ bool pivot_step_valid(int kt, int nk) { return 4 * (k
 
 // `tid` = index of the thread inside its 256-thread elimination group (= threadIdx.x when the group is the workgroup),
 // `barrier()` synchronises the four wavefronts of the group.
-template <int NR, int KB, class Barrier>
+template <int NR, int KB, int RW, class Barrier>
 __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bool &singular, int D, int seq,
-                                                cplx (*rowbuf)[64], PivotRecord *pivrec, int *permseq, int *weak, int tid,
+                                                cplx (*rowbuf)[RW], PivotRecord *pivrec, int *permseq, int *weak, int tid,
                                                 Barrier &&barrier) {
     const int ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;
     const int nk = min(16, D - 16 * KB);
     bool live = 16 * KB + tj < D;
     barrier();
-    if (ti == 0) publish_pivot_row<NR, KB>(m, live, 0, seq, rowbuf, pivrec, permseq, weak, tid);
+    if (ti == 0) publish_pivot_row<NR, KB, RW>(m, live, 0, seq, rowbuf, pivrec, permseq, weak, tid);
     for (int kt = 0; kt < 16; ++kt) {
         if (!pivot_step_valid(kt, nk)) continue;
         int next = kt + 1;
@@ -191,13 +218,26 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bo
         if (ti <= kt) c[KB] = c_make(0.0, 0.0);
 #pragma unroll
         for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
-        if (next < 16 && ti == next) publish_pivot_row<NR, KB>(m, live, next, seq, rowbuf, pivrec, permseq, weak, tid);
+        if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, live, next, seq, rowbuf, pivrec, permseq, weak, tid);
 #pragma unroll
         for (int ra = KB + 1; ra < NR; ++ra) {
 #pragma unroll
             for (int rb = KB; rb < NR; ++rb) m[ra][rb] = c_fnma(c[ra], r[rb], m[ra][rb]);
         }
     }
+}
+
+// sign of the permutation row s -> perm[s], s < D <= 128 (cycle decomposition; one thread)
+__device__ __forceinline__ bool permutation_is_odd(const int *perm, int D) {
+    unsigned long long seen[2] = {0ull, 0ull};
+    int transpositions = 0;
+    for (int s = 0; s < D; ++s) {
+        if ((seen[s >> 6] >> (s & 63)) & 1ull) continue;
+        int len = 0, x = s;
+        while (!((seen[x >> 6] >> (x & 63)) & 1ull)) { seen[x >> 6] |= 1ull << (x & 63); x = perm[x]; ++len; }
+        transpositions += len - 1;
+    }
+    return (transpositions & 1) != 0;
 }
 
 }  // namespace

@@ -145,10 +145,10 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
 #endif
         if (!skip_lu) {
             auto wg_barrier = [] { __syncthreads(); };
-            eliminate_block<NR, 0>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0)>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0)>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0)>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            eliminate_block<NR, 0, 64>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0), 64>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0), 64>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0), 64>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
         }
         __syncthreads();
         if (tid == 0 && weak && A.st.flags && !skip_lu) {

@@ -58,3 +58,39 @@ def test_dense_mono_step_matches_torch(D):
     assert float((got - want).abs().max() / want.abs().max()) < 1e-13
     assert float((c2.cpu() - c2_want).abs().max() / c2_want.abs().max()) < 1e-10
     assert np.all(sgn.cpu().numpy() == 1.0)               # previous c2 = 1: the branch tracker must not flip
+
+
+@pytest.mark.parametrize("D", [40, 70, 96])
+def test_register_prefactor_and_its_weak_pivot_fallback(D):
+    """diagonal width matrices: the determinant of the dense path is taken in registers (block-pivoted elimination,
+    dense_prefactor_reg_kernel); monodromy blocks whose large entries lie outside the diagonal 16-column blocks defeat the
+    in-block pivoting -- those trajectories are flagged and redone by the fully pivoted LDS elimination"""
+    from semiclassical_amd import propagators as PR
+    from semiclassical_amd._lib import lib, check
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(D)
+    n = 9
+    G = torch.diag(torch.from_numpy(rng.uniform(0.5, 2.0, D)))
+    q0 = torch.zeros(D)
+    prop = PR.HermanKlukPropagator(G, G, device="cuda")
+    prop.initial_conditions(q0, q0, G, ntraj=n, generator=torch.Generator().manual_seed(1))
+    st = torch.sqrt(torch.diagonal(G)).numpy()
+    for shift in (0, 20):
+        blocks = []
+        for _ in range(4):
+            b = rng.uniform(-0.2, 0.2, (n, D, D))
+            b += np.roll(np.eye(D), shift, axis=1)[None] * rng.uniform(1.0, 2.0, (n, D, 1))
+            blocks.append(b)
+        prop._set_mono_layout(0)
+        prop._mono.copy_(torch.from_numpy(np.stack(blocks, axis=1)).cuda())
+        check(lib.sc_dense_mono_step(prop._state, prop._hk, None, None, prop._mono_sums_ptr(), 0.0, 1, prop._stream()))
+        torch.cuda.synchronize()
+        mqq, mqp, mpq, mpp = blocks
+        scale_a, scale_b = st[None, :, None], st[None, None, :]
+        mat = 0.5 * (scale_a / scale_b * mqq + scale_b / scale_a * mpp - 1j * scale_a * scale_b * mqp + 1j * mpq / (scale_a * scale_b))
+        want = np.linalg.det(mat)
+        got = prop._c2.cpu().numpy()
+        assert np.max(np.abs(got - want) / np.abs(want)) < 1e-10, shift
+        flagged = int(prop._flags[-1].item())
+        assert int(prop._flags[:-1].sum().item()) == 0                  # the fix-up pass clears the flags it served
+        assert (flagged > 0) == (shift > 0), (shift, flagged)      # weak in-block pivots occur only for the shifted blocks

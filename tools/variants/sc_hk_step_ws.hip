@@ -203,10 +203,10 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
         cplx det = c_make(1.0, 0.0);
         bool singular = false;
 #ifndef WS_ABLATE_LU
-        eliminate_block<NR, 0>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 1>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 2>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 3>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 0, 64>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 1, 64>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 2, 64>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 3, 64>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, weak, ltid, barrier);
 #else
         det = m[0][0];
 #endif
