@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        7
+#define SC_ABI_VERSION        8
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -58,6 +58,11 @@ typedef struct sc_potential {
     const double *par2;     /*                                                            DENSE: hess0[D][D]  */
     double        scalar0;  /*                                                            DENSE: energy0 - origin */
     const double *inv_mass; /* 1/m [D]                                 potentials.py:261-263, 549 */
+    const double *lin_prop; /* DENSE, optional (may be NULL): the RK4 step matrix Phi[2D][2D] = sum_{k<=4} (lin_dt G)^k / k!
+                               of the monodromy equations, G = [[0, diag 1/m], [-hess0, 0]] (row-major).  One RK4
+                               step of a linear constant-coefficient system is the product with Phi; sc_hk_step
+                               uses it for its small-D register kernel when lin_dt equals the step it is called with. */
+    double        lin_dt;
 } sc_potential;
 
 /* Storage order of the 4 D^2 doubles mono[i] of one trajectory.

@@ -15,7 +15,8 @@ c_double_p = C.c_void_p      # device pointers travel as plain integers
 class sc_potential(C.Structure):
     _fields_ = [("kind", C.c_int32), ("dim", C.c_int32),
                 ("par0", c_double_p), ("par1", c_double_p), ("par2", c_double_p),
-                ("scalar0", C.c_double), ("inv_mass", c_double_p)]
+                ("scalar0", C.c_double), ("inv_mass", c_double_p),
+                ("lin_prop", c_double_p), ("lin_dt", C.c_double)]
 
 
 class sc_state(C.Structure):
@@ -72,7 +73,7 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 7              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 8              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 

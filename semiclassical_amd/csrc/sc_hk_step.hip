@@ -289,6 +289,11 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     StepArgs a{*pot, *st, *hk, dt, mode, energy_partials};
     const int threads = step_threads(D), grid = sc_step_grid(st->n, D);
     hipStream_t s = (hipStream_t)stream;
+    // constant Hessian, D <= 16 and the step matrix Phi(dt) at hand: the register kernel of sc_hk_step_lin.hip
+    if (dense && D <= 16 && (mode == 1 || (mode == 0 && pot->lin_prop && pot->lin_dt == dt))) {
+        const int rc = sc_launch_step_lin(a, grid, s);
+        if (rc != 0) return rc < 0 ? rc : SC_OK;
+    }
     if (dense) {
         if (hipFuncSetAttribute((const void *)hk_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)

@@ -29,9 +29,22 @@ class _DescriptorMixin(object):
     """caches the device copies of the parameter vectors per device; a cached block is reused only while the host
     parameters it was built from are unchanged (omega, chi, masses ... edited in place rebuild it)"""
 
-    def _descriptor(self, device):
+    def _descriptor(self, device, dt=None):
+        """``dt``: the time step the descriptor will be used with -- potentials with a constant Hessian attach the RK4
+        step matrix of the monodromy equations for it (``sc_potential.lin_prop``)"""
         cache = self.__dict__.setdefault("_desc_cache", {})
         key = str(device)
+        if dt is not None and self._step_matrix(0.0) is not None:
+            base = self._descriptor(device)
+            steps = cache[key][4]
+            if dt not in steps:
+                if len(steps) > 8:
+                    steps.clear()
+                phi = torch.from_numpy(self._step_matrix(dt)).contiguous().to(device)
+                d = sc_potential.from_buffer_copy(base)
+                d.lin_prop, d.lin_dt = ptr(phi), float(dt)
+                steps[dt] = (d, phi)
+            return steps[dt][0]
         kind, par0, par1, par2, scalar0 = self._parameters()
         host = [None if x is None else torch.as_tensor(x, dtype=torch.float64).detach().cpu()
                 for x in (par0, par1, par2, self.masses())]
@@ -45,8 +58,13 @@ class _DescriptorMixin(object):
         bufs = [up(host[0]), up(host[1]), up(host[2]), up(1.0 / host[3])]
         desc = sc_potential(kind=kind, dim=self.dimensions(), par0=ptr(bufs[0]), par1=ptr(bufs[1]),
                             par2=ptr(bufs[2]), scalar0=float(scalar0), inv_mass=ptr(bufs[3]))
-        cache[key] = (desc, bufs, stamp, [None if h is None else h.clone() for h in host])   # bufs keeps the memory alive
+        # bufs keeps the memory alive; the last entry holds the per-dt descriptors derived from this one
+        cache[key] = (desc, bufs, stamp, [None if h is None else h.clone() for h in host], {})
         return desc
+
+    def _step_matrix(self, dt):
+        """None: the Hessian depends on the position.  Constant-Hessian potentials return Phi(dt) (2D x 2D)."""
+        return None
 
     def _invalidate_descriptor(self):
         self.__dict__.pop("_desc_cache", None)
@@ -223,6 +241,20 @@ class MolecularHarmonicPotential(_MolecularPotentialBase):
     def _parameters(self):
         return (_lib.SC_POT_HARMONIC_DENSE, self.pos0, self.grad0, self.hess0,
                 float(self.energy0) - self._origin)
+
+    def _step_matrix(self, dt):
+        """RK4 of the linear system d/dt [X; Y] = G [X; Y], G = [[0, 1/m], [-hess0, 0]] (the monodromy equations of
+        reference propagators.py:342-357 with a constant Hessian) is the product with
+        Phi = 1 + hG + (hG)^2/2 + (hG)^3/6 + (hG)^4/24: the four stages of propagators.py:86-119 written out"""
+        D = self._dim
+        if D > 16:
+            return None              # the kernel that takes Phi holds D <= 16
+        G = np.zeros((2 * D, 2 * D), dtype=np.longdouble)
+        G[:D, D:] = np.diag(1.0 / self._masses.numpy().astype(np.longdouble))
+        G[D:, :D] = -self.hess0.numpy().astype(np.longdouble)
+        hG, one = np.longdouble(dt) * G, np.eye(2 * D, dtype=np.longdouble)
+        phi = one + hG @ (one + hG @ (one + hG @ (one + hG / 4) / 3) / 2)
+        return np.ascontiguousarray(phi.astype(np.float64))
 
     def harmonic_approximation(self, r):
         dev = r.device

@@ -243,7 +243,7 @@ class HermanKlukPropagator(object):
             nblocks = self._launch_generic_step(potential, dt, s)
         else:
             if desc is None:
-                desc = self._potential_descriptor(potential)
+                desc = self._potential_descriptor(potential, dt)
             if self._shortcut_applies(desc):
                 check(lib.sc_hk_step_diag(desc, self._state, self._hk, ptr(self._mdiag), dt, 0, ptr(self._epart), s))
                 self._mono_stale = True
@@ -360,12 +360,12 @@ class HermanKlukPropagator(object):
     def _after_prefactor(self, track):
         """hook for propagators whose prefactor needs more than the HK determinant (WM)"""
 
-    def _potential_descriptor(self, potential):
+    def _potential_descriptor(self, potential, dt=None):
         if not hasattr(potential, "_descriptor"):
             raise TypeError(f"{type(potential).__name__} has no device descriptor: it takes the unfused path "
                             "(_launch_generic_step), not a fused kernel")
         with torch.cuda.device(self.device):
-            return potential._descriptor(self.device)
+            return potential._descriptor(self.device) if dt is None else potential._descriptor(self.device, dt)
 
     def _check_energy_guard(self):
         """raise the reference's RuntimeError (propagators.py:396) if <T+V> jumped by more than 1e-2 Hartree"""
@@ -477,7 +477,7 @@ class HermanKlukPropagator(object):
         t0 = self.t
         base = slots.data_ptr()
         fused = hasattr(potential, "_descriptor") and not hasattr(potential, "_gdml_model") and self.dim <= 64
-        desc = self._potential_descriptor(potential) if fused else None
+        desc = self._potential_descriptor(potential, dt) if fused else None
         if use_graph and fused and nt > 2 and not getattr(self, "profile_step_kernel", False) and not self.kernel_timing:
             self._run_graph(potential, dt, nt, desc, slots)
         else:

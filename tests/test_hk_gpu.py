@@ -349,3 +349,49 @@ def test_tiled_monodromy_layout_roundtrip_and_parity(D):
     a._state.mono_layout = _lib.SC_MONO_TILED16
     with pytest.raises(_lib.EngineError, match="tiled monodromy layout"):
         check(lib.sc_state_to_reference(a._state, _lib.ptr(ya), None))
+
+
+@pytest.mark.parametrize("D,zero_modes,diag", [(12, 6, False), (12, 0, True), (9, 6, False), (9, 0, True),
+                                               (6, 0, True), (6, 0, False), (3, 0, True), (5, 0, True)])
+def test_constant_hessian_register_kernel_vs_oracle(D, zero_modes, diag):
+    """dense constant Hessian (MolecularHarmonicPotential) on random couplings: the shapes of the register kernel that
+    multiplies with the RK4 step matrix (sc_hk_step_lin.hip), diagonal and projected prefactor, against the oracle's
+    staged RK4; (5, 0, True) is not instantiated and checks the hand-over to the general kernel"""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(100 * D + zero_modes + diag)
+    n, nt, dt = 150, 10, 4.0
+    masses = rng.uniform(1800.0, 22000.0, D)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    om = rng.uniform(500, 3000, D) / 219474.63
+    sm = np.sqrt(masses)
+    hess0 = (Q * om ** 2) @ Q.T * np.outer(sm, sm)
+    hess0 = 0.5 * (hess0 + hess0.T)
+    pos0, grad0 = rng.normal(0, 0.1, D), rng.normal(0, 1e-3, D)
+    nac0 = rng.normal(0, 1e-2, D)
+    args = (pos0, np.float64(-0.3), grad0, hess0, masses, nac0)
+    w = om * rng.uniform(0.7, 1.4, D)
+    if diag:
+        G = np.diag(w * masses)
+    else:
+        w[:zero_modes] = 0.0
+        U, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        G = (U * w) @ U.T * np.outer(sm, sm)
+        G = 0.5 * (G + G.T)
+    G = torch.from_numpy(G)
+    q0, p0 = torch.from_numpy(pos0 + rng.normal(0, 0.05, D)), torch.zeros(D)
+    ref, prop = orc.HKOracle(G, G), PR.HermanKlukPropagator(G, G, device="cuda")
+    torch.manual_seed(3)
+    ref.initial_conditions(q0, p0, G, ntraj=n)
+    rc, rk = orc.run_loop(ref, orc.MolecularHarmonicOracle(*args, origin=-0.3), dt, nt, 0.01)
+    prop.set_initial_conditions(q0, p0, G, ref.zi, ref.probi)
+    assert prop._pre.dprime == D - zero_modes and bool(prop._pre.diag) == diag
+    pot = P.MolecularHarmonicPotential.from_arrays(*args, origin=-0.3)
+    c, k = prop.run(pot, dt, nt, 0.01)
+    assert cases.rel_err(c, rc) < TOL and cases.rel_err(k, rk) < TOL
+    for a, b in zip(prop.current_positions_and_momenta() + prop.monodromy_matrices(),
+                    ref.current_positions_and_momenta() + ref.monodromy_matrices()):
+        assert cases.rel_err(a.cpu(), b) < 1e-11
+    assert cases.rel_err(prop.classical_action().cpu(), ref.classical_action()) < 1e-11
+    assert abs(prop.mean_energy() - float(ref.eom.en_mean)) < 1e-11 * max(1.0, abs(float(ref.eom.en_mean)))

@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.sc_struct_size(b"no_such_struct") == -1
     # struct sizes agree with the C layout (LP64): a mismatch would shift every pointer
     assert ctypes.sizeof(_lib.sc_state) == 8 + 4 + 4 + 7 * 8
-    assert ctypes.sizeof(_lib.sc_potential) == 4 + 4 + 3 * 8 + 8 + 8
+    assert ctypes.sizeof(_lib.sc_potential) == 4 + 4 + 3 * 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.sc_hk_consts) == 16 + 6 * 8
     assert ctypes.sizeof(_lib.sc_overlap_consts) == 8 + 5 * 8 + 8
     assert ctypes.sizeof(_lib.sc_nac_consts) == 8 + 4 * 8 + 16
@@ -144,3 +144,29 @@ def test_fchk_reader_methylium():
     assert np.linalg.matrix_rank(G0, tol=1e-8) == 6
     g = cases.load("hk_methylium")
     assert cases.rel_err(G0, g["Gamma_0"]) < 1e-12 and cases.rel_err(x0, g["q0"]) < 1e-15
+
+
+def test_rk4_step_matrix_of_constant_hessian_equals_staged_rk4():
+    """MolecularHarmonicPotential._step_matrix: Phi(dt) applied to random monodromy blocks = the oracle's four RK4
+    stages of the same linear equations (reference propagators.py:86-119, 342-357)"""
+    import numpy as np
+    from semiclassical_amd import potentials as P
+    rng = np.random.default_rng(2)
+    D, dt = 7, 5.0
+    masses = rng.uniform(1800, 20000, D)
+    H = rng.standard_normal((D, D)) * 0.2
+    H = H @ H.T
+    pot = P.MolecularHarmonicPotential.from_arrays(np.zeros(D), np.float64(0.0), np.zeros(D), H, masses, np.zeros(D))
+    phi = pot._step_matrix(dt)
+    assert phi.shape == (2 * D, 2 * D) and P.MorsePotential._step_matrix(pot, dt) is None
+    y = rng.standard_normal((2 * D, 2 * D))
+    G = np.block([[np.zeros((D, D)), np.diag(1 / masses)], [-H, np.zeros((D, D))]])
+    k1 = G @ y
+    k2 = G @ (y + 0.5 * dt * k1)
+    k3 = G @ (y + 0.5 * dt * k2)
+    k4 = G @ (y + dt * k3)
+    staged = y + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+    assert np.max(np.abs(phi @ y - staged)) < 1e-14 * np.max(np.abs(staged))
+    big = P.MolecularHarmonicPotential.from_arrays(np.zeros(20), np.float64(0.0), np.zeros(20), np.eye(20),
+                                                   np.ones(20), np.zeros(20))
+    assert big._step_matrix(dt) is None            # the kernel taking Phi holds D <= 16
