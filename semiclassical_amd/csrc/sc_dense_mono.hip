@@ -403,11 +403,11 @@ __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
 // The LDS kernel above needs 16 d'^2 bytes per trajectory (one workgroup per CU at D = 90) and two barriers per pivot:
 // 10 ms at D = 90, n = 1e4.  Trajectories whose in-block pivot is too weak are flagged and redone by the LDS kernel.
 template <int NR, int KB, int RW, class Barrier>
-__device__ __forceinline__ void eliminate_all_blocks(cplx (&m)[NR][NR], cplx &det, bool &singular, int D, int seq0, cplx (*rowbuf)[RW],
+__device__ __forceinline__ void eliminate_all_blocks(cplx (&m)[NR][NR], cplx &det, int D, int seq0, cplx (*rowbuf)[RW],
                                                      PivotRecord *pivrec, int *permseq, int *weak, int tid, Barrier &&barrier) {
     if constexpr (KB < NR) {
-        eliminate_block<NR, KB, RW>(m, det, singular, D, seq0 + 1 + KB, rowbuf, pivrec, permseq, weak, tid, barrier);
-        eliminate_all_blocks<NR, KB + 1, RW>(m, det, singular, D, seq0, rowbuf, pivrec, permseq, weak, tid, barrier);
+        eliminate_block<NR, KB, RW>(m, det, D, seq0 + 1 + KB, rowbuf, pivrec, permseq, weak, tid, barrier);
+        eliminate_all_blocks<NR, KB + 1, RW>(m, det, D, seq0, rowbuf, pivrec, permseq, weak, tid, barrier);
     }
 }
 
@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
     __shared__ cplx rowbuf[16][RW];
     __shared__ PivotRecord pivrec[16];
     __shared__ int permseq[RW];
-    __shared__ int weak;
+    __shared__ cplx detbuf[16];
+    __shared__ int weak;                     // bit 0: weak in-block pivot, bit 1: zero pivot
     __shared__ double scl[4 * RW];           // st, 1/st, si, 1/si
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x, tj = tid & 15;
     const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);
@@ -460,16 +461,15 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
             }
         }
         cplx det = c_make(1.0, 0.0);
-        bool singular = false;
-        eliminate_all_blocks<NR, 0, RW>(m, det, singular, D, seq0, rowbuf, pivrec, permseq, &weak, tid, barrier);
+        eliminate_all_blocks<NR, 0, RW>(m, det, D, seq0, rowbuf, pivrec, permseq, &weak, tid, barrier);
+        post_pivot_product(det, detbuf, tid);
         __syncthreads();
         if (tid == 0) {
             if (weak) {
                 A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted LDS elimination
                 atomicAdd(&A.st.flags[A.st.n], 1);
             } else {
-                if (singular) det = c_make(0.0, 0.0);
-                else if (permutation_is_odd(permseq, D)) det = c_make(-det.x, -det.y);
+                det = finish_determinant(detbuf, permseq, D);
                 cplx *c2 = (cplx *)A.st.c2;
                 if (A.mode == 0) {
                     const cplx prev = c2[tr];

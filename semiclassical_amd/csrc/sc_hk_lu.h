@@ -39,8 +39,7 @@ __device__ __forceinline__ cplx c_inv_fast(cplx z) {
 }
 
 struct PivotRecord {        // published by the owner of row k together with the scaled row
-    double re, im;          // pivot value
-    int col, pad;           // pivot column
+    int col, pad;           // pivot column; tag
 };
 
 // Pivot-column entries of the N = NR-KB live row slots from lane pl (wave-uniform, run-time) of every 16-lane DPP
@@ -131,10 +130,12 @@ __device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[
 // The 16 lanes that own row k = 16*KB + kt pick the pivot column among the live columns of the diagonal block,
 // scale the row by 1/pivot and publish it: row -> rowbuf[kt], pivot -> pivrec[kt], and LAST the record's tag
 // (= seq), which the consumers poll.  LDS operations of one wave execute in issue order, so a consumer that sees
-// the tag sees the row.  Runs inside `if (ti == kt)`.
+// the tag sees the row.  Runs inside `if (ti == kt)`: only the 16 owner lanes multiply the pivot into their `det`
+// (every row group accumulates the pivots of its own rows, the caller multiplies the 16 partial products at the end)
+// and a zero pivot sets bit 1 of *weak -- the consumers carry neither the determinant nor a singularity flag.
 template <int NR, int KB, int RW>
-__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool live, int kt, int seq, cplx (*rowbuf)[RW],
-                                                  PivotRecord *pivrec, int *permseq, int *weak, int tid) {
+__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx &det, bool live, int kt, int seq,
+                                                  cplx (*rowbuf)[RW], PivotRecord *pivrec, int *permseq, int *weak, int tid) {
     const int tj = tid & 15, lane = tid & 63;
     const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);       // the matrix row (within the block) this thread holds
     // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj)
@@ -146,13 +147,15 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool 
     const int pl = 15 - (key_blk & 15);
     const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | pl);
     const cplx inv = c_make(readlane_f64(myinv.x, src), readlane_f64(myinv.y, src));
+    det = c_mul(det, c_make(readlane_f64(m[KB][KB].x, src), readlane_f64(m[KB][KB].y, src)));
     const bool keep = live && tj != pl;
     const cplx r0 = c_mul(m[KB][KB], inv);
     rowbuf[kt][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
 #pragma unroll
     for (int rb = KB + 1; rb < NR; ++rb) rowbuf[kt][16 * rb + tj] = c_mul(m[KB][rb], inv);
     if (tj == pl) {                                       // the winner publishes the pivot itself
-        pivrec[kt].re = m[KB][KB].x; pivrec[kt].im = m[KB][KB].y; pivrec[kt].col = 16 * KB + pl;
+        pivrec[kt].col = 16 * KB + pl;
+        if (m[KB][KB].x == 0.0 && m[KB][KB].y == 0.0) atomicOr(weak, 2);      // singular: det = 0
         permseq[16 * KB + trow] = 16 * KB + pl;          // row -> pivot column (the sign of this permutation enters c2)
         __asm__ volatile("" ::: "memory");
         __hip_atomic_store(&pivrec[kt].pad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -163,7 +166,7 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], bool 
         int key_out = -1;
 #pragma unroll
         for (int rb = KB + 1; rb < NR; ++rb) key_out = max(key_out, __double2hiint(c_abs2(m[KB][rb])));
-        if ((key_out & ~15) - (key_blk & ~15) > (8 << 20)) *weak = 1;
+        if ((key_out & ~15) - (key_blk & ~15) > (8 << 20)) atomicOr(weak, 1);
     }
 }
 
@@ -184,47 +187,59 @@ __device__ __forceinline__ bool pivot_step_valid(int kt, int nk) { return 4 * (k
 
 // `tid` = index of the thread inside its 256-thread elimination group (= threadIdx.x when the group is the workgroup),
 // `barrier()` synchronises the four wavefronts of the group.
+// `det`: this thread's partial product of pivots (see publish_pivot_row); start it at 1 and hand the same variable to
+// every block.
 template <int NR, int KB, int RW, class Barrier>
-__device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, bool &singular, int D, int seq,
+__device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, int D, int seq,
                                                 cplx (*rowbuf)[RW], PivotRecord *pivrec, int *permseq, int *weak, int tid,
                                                 Barrier &&barrier) {
     const int ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;
     const int nk = min(16, D - 16 * KB);
     bool live = 16 * KB + tj < D;
     barrier();
-    if (ti == 0) publish_pivot_row<NR, KB, RW>(m, live, 0, seq, rowbuf, pivrec, permseq, weak, tid);
+    if (ti == 0) publish_pivot_row<NR, KB, RW>(m, det, live, 0, seq, rowbuf, pivrec, permseq, weak, tid);
     for (int kt = 0; kt < 16; ++kt) {
         if (!pivot_step_valid(kt, nk)) continue;
         int next = kt + 1;
         while (next < 16 && !pivot_step_valid(next, nk)) ++next;
-        double re, im;
         int col;
         cplx r[NR];
         for (;;) {
             const int tag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pivrec[kt].pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             __asm__ volatile("" ::: "memory");
-            re = pivrec[kt].re; im = pivrec[kt].im; col = pivrec[kt].col;
+            col = pivrec[kt].col;
 #pragma unroll
             for (int rb = KB; rb < NR; ++rb) r[rb] = rowbuf[kt][16 * rb + tj];
             __asm__ volatile("" ::: "memory");
             if (tag == seq) break;
         }
-        singular = singular || (re == 0.0 && im == 0.0);
-        if (tid < 64) det = c_mul(det, c_make(re, im));
         const int pl = col & 15;
         live = live && tj != pl;
         cplx c[NR];
+        // rows of this block that have been pivot rows already are updated like the others: nothing reads them again
         column_fetch<NR, KB>(m, c, pl);
-        if (ti <= kt) c[KB] = c_make(0.0, 0.0);
 #pragma unroll
         for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
-        if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, live, next, seq, rowbuf, pivrec, permseq, weak, tid);
+        if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, det, live, next, seq, rowbuf, pivrec, permseq, weak, tid);
 #pragma unroll
         for (int ra = KB + 1; ra < NR; ++ra) {
 #pragma unroll
             for (int rb = KB; rb < NR; ++rb) m[ra][rb] = c_fnma(c[ra], r[rb], m[ra][rb]);
         }
     }
+}
+
+// The 16 row groups' partial pivot products -> detbuf[16] (call before the barrier that ends the elimination) ...
+__device__ __forceinline__ void post_pivot_product(cplx det, cplx *detbuf, int tid) {
+    if ((tid & 15) == 0) detbuf[tid >> 4] = det;
+}
+// ... and their product times the sign of the column permutation (one thread, after that barrier)
+__device__ __forceinline__ bool permutation_is_odd(const int *perm, int D);
+__device__ __forceinline__ cplx finish_determinant(const cplx *detbuf, const int *permseq, int D) {
+    cplx det = detbuf[0];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) det = c_mul(det, detbuf[g]);
+    return permutation_is_odd(permseq, D) ? c_make(-det.x, -det.y) : det;
 }
 
 // sign of the permutation row s -> perm[s], s < D <= 128 (cycle decomposition; one thread)

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     __shared__ cplx rowbuf[16][64];
     __shared__ PivotRecord pivrec[16];
     __shared__ int permseq[64];
-    __shared__ int weak;
+    __shared__ cplx detbuf[16];              // partial pivot products of the 16 row groups
+    __shared__ int weak;                     // bit 0: weak in-block pivot (-> pivoted fallback), bit 1: zero pivot
 
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
     const int tj = tid & 15;
@@ -136,8 +137,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         }
 
         // ---------------- phase C: determinant in registers ----------------
-        cplx det = c_make(1.0, 0.0);
-        bool singular = false;
+        cplx det = c_make(1.0, 0.0);             // this row group's share of the product of pivots
 #ifdef SC_TUNING
         const bool skip_lu = (A.mode & 0x100) != 0;      // tuning build only: phase ablation (SC_DEBUG_SKIP_LU)
 #else
@@ -145,38 +145,26 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
 #endif
         if (!skip_lu) {
             auto wg_barrier = [] { __syncthreads(); };
-            eliminate_block<NR, 0, 64>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0), 64>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0), 64>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0), 64>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0), 64>(m, det, D, seq0 + 2, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0), 64>(m, det, D, seq0 + 3, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0), 64>(m, det, D, seq0 + 4, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
         }
+        post_pivot_product(det, detbuf, tid);
         __syncthreads();
-        if (tid == 0 && weak && A.st.flags && !skip_lu) {
+        if (tid == 0 && (weak & 1) && A.st.flags && !skip_lu) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
             atomicAdd(&A.st.flags[A.st.n], 1);   // lets the fix-up launch return at once when nothing was flagged
         } else if (tid == 0) {
-            if (singular) {
-                det = c_make(0.0, 0.0);
-            } else {
-                // sign of the column permutation k -> permseq[k]
-                unsigned long long seen = 0ull;
-                int transpositions = 0;
-                for (int s = 0; s < D; ++s) {
-                    if ((seen >> s) & 1ull) continue;
-                    int len = 0, x = s;
-                    while (!((seen >> x) & 1ull)) { seen |= 1ull << x; x = permseq[x]; ++len; }
-                    transpositions += len - 1;
-                }
-                if (transpositions & 1) det = c_make(-det.x, -det.y);
-            }
+            const cplx c2new = (weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf, permseq, D);
             cplx *c2 = (cplx *)A.st.c2;
             if (do_step) {
                 const cplx prev = c2[tr];
-                if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
+                if (prev.x < 0.0 && c2new.x < 0.0 && prev.y * c2new.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
             } else {
                 A.st.sgn[tr] = 1.0;
             }
-            c2[tr] = det;
+            c2[tr] = c2new;
         }
         __syncthreads();
     }

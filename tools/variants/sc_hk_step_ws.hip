@@ -42,6 +42,7 @@ struct WsLds {
     PivotRecord pivrec[WS_GROUPS][16];
     int permseq[WS_GROUPS][64];
     int weak[WS_GROUPS];
+    cplx detbuf[WS_GROUPS][16];
     int bar[WS_GROUPS];                       // monotonic arrival counters of the group barriers
     int full[4];                              // hand-over tags, one per wavefront position
     int err;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
     cplx (*rowbuf)[64] = S.rowbuf[g];
     PivotRecord *pivrec = S.pivrec[g];
     int *permseq = S.permseq[g], *weak = &S.weak[g];
+    cplx *detbuf = S.detbuf[g];
     int bar_target = 0, seq0 = 0;
     auto barrier = [&] { group_barrier(&S.bar[g], bar_target, lane, &S.err); };
     int k = g;
@@ -201,37 +203,25 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
         __asm__ volatile("" ::: "memory");
 
         cplx det = c_make(1.0, 0.0);
-        bool singular = false;
 #ifndef WS_ABLATE_LU
-        eliminate_block<NR, 0, 64>(m, det, singular, D, seq0 + 1, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 1, 64>(m, det, singular, D, seq0 + 2, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 2, 64>(m, det, singular, D, seq0 + 3, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 3, 64>(m, det, singular, D, seq0 + 4, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 1, 64>(m, det, D, seq0 + 2, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 2, 64>(m, det, D, seq0 + 3, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 3, 64>(m, det, D, seq0 + 4, rowbuf, pivrec, permseq, weak, ltid, barrier);
 #else
         det = m[0][0];
 #endif
+        post_pivot_product(det, detbuf, ltid);
         barrier();
         if (ltid == 0) {
             cplx *c2 = (cplx *)A.st.c2;
             if (lds_load(&S.err)) {
                 c2[tr] = c_make(__builtin_nan(""), __builtin_nan(""));         // protocol failure: never silently wrong
-            } else if (*weak && A.st.flags) {
+            } else if ((*weak & 1) && A.st.flags) {
                 A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
                 atomicAdd(&A.st.flags[A.st.n], 1);
             } else {
-                if (singular) {
-                    det = c_make(0.0, 0.0);
-                } else {
-                    unsigned long long seen = 0ull;
-                    int transpositions = 0;
-                    for (int s = 0; s < D; ++s) {
-                        if ((seen >> s) & 1ull) continue;
-                        int len = 0, x = s;
-                        while (!((seen >> x) & 1ull)) { seen |= 1ull << x; x = permseq[x]; ++len; }
-                        transpositions += len - 1;
-                    }
-                    if (transpositions & 1) det = c_make(-det.x, -det.y);
-                }
+                det = (*weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf, permseq, D);
                 const cplx prev = c2[tr];
                 if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
                 c2[tr] = det;
