@@ -404,10 +404,10 @@ __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
 // 10 ms at D = 90, n = 1e4.  Trajectories whose in-block pivot is too weak are flagged and redone by the LDS kernel.
 template <int NR, int KB, int RW, class Barrier>
 __device__ __forceinline__ void eliminate_all_blocks(cplx (&m)[NR][NR], cplx &det, int D, int seq0, cplx (*rowbuf)[RW],
-                                                     PivotRecord *pivrec, int *permseq, int *weak, int tid, Barrier &&barrier) {
+                                                     PivotRecord *pivrec, int *weak, int tid, Barrier &&barrier) {
     if constexpr (KB < NR) {
-        eliminate_block<NR, KB, RW>(m, det, D, seq0 + 1 + KB, rowbuf, pivrec, permseq, weak, tid, barrier);
-        eliminate_all_blocks<NR, KB + 1, RW>(m, det, D, seq0, rowbuf, pivrec, permseq, weak, tid, barrier);
+        eliminate_block<NR, KB, RW>(m, det, D, seq0 + 1 + KB, rowbuf, pivrec, weak, tid, barrier);
+        eliminate_all_blocks<NR, KB + 1, RW>(m, det, D, seq0, rowbuf, pivrec, weak, tid, barrier);
     }
 }
 
@@ -416,7 +416,6 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
     constexpr int RW = 16 * NR;
     __shared__ cplx rowbuf[16][RW];
     __shared__ PivotRecord pivrec[16];
-    __shared__ int permseq[RW];
     __shared__ cplx detbuf[16];
     __shared__ int weak;                     // bit 0: weak in-block pivot, bit 1: zero pivot
     __shared__ double scl[4 * RW];           // st, 1/st, si, 1/si
@@ -429,6 +428,7 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
     }
     __syncthreads();
     auto barrier = [] { __syncthreads(); };
+    const bool rows_odd = row_order_is_odd(D);
     const unsigned to = (unsigned)(trow * D + tj);
     int seq0 = 0;
     for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += NR) {
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
             }
         }
         cplx det = c_make(1.0, 0.0);
-        eliminate_all_blocks<NR, 0, RW>(m, det, D, seq0, rowbuf, pivrec, permseq, &weak, tid, barrier);
+        eliminate_all_blocks<NR, 0, RW>(m, det, D, seq0, rowbuf, pivrec, &weak, tid, barrier);
         post_pivot_product(det, detbuf, tid);
         __syncthreads();
         if (tid == 0) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
                 A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted LDS elimination
                 atomicAdd(&A.st.flags[A.st.n], 1);
             } else {
-                det = finish_determinant(detbuf, permseq, D);
+                det = finish_determinant(detbuf, rows_odd);
                 cplx *c2 = (cplx *)A.st.c2;
                 if (A.mode == 0) {
                     const cplx prev = c2[tr];

@@ -135,9 +135,8 @@ __device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[
 // and a zero pivot sets bit 1 of *weak -- the consumers carry neither the determinant nor a singularity flag.
 template <int NR, int KB, int RW>
 __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx &det, bool live, int kt, int seq,
-                                                  cplx (*rowbuf)[RW], PivotRecord *pivrec, int *permseq, int *weak, int tid) {
+                                                  cplx (*rowbuf)[RW], PivotRecord *pivrec, int *weak, int tid) {
     const int tj = tid & 15, lane = tid & 63;
-    const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);       // the matrix row (within the block) this thread holds
     // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj)
     const int blk = (__double2hiint(c_abs2(m[KB][KB])) & ~15) | (15 - tj);
     int key_blk = live ? blk : -1;
@@ -147,7 +146,15 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
     const int pl = 15 - (key_blk & 15);
     const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | pl);
     const cplx inv = c_make(readlane_f64(myinv.x, src), readlane_f64(myinv.y, src));
-    det = c_mul(det, c_make(readlane_f64(m[KB][KB].x, src), readlane_f64(m[KB][KB].y, src)));
+    // sign of the column choice: the pivot column is the p-th of the live ones (p = live columns to its left; only the
+    // 16 owner lanes are active, so the ballot holds exactly their `live` bits) = p adjacent transpositions
+    const unsigned long long lm = __ballot(live);
+    const int flip = (__popcll(lm & ((1ull << src) - 1ull)) & 1) << 31;
+    const cplx piv = c_make(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m[KB][KB].x), src) ^ flip,
+                                             __builtin_amdgcn_readlane(__double2loint(m[KB][KB].x), src)),
+                            __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m[KB][KB].y), src) ^ flip,
+                                             __builtin_amdgcn_readlane(__double2loint(m[KB][KB].y), src)));
+    det = c_mul(det, piv);
     const bool keep = live && tj != pl;
     const cplx r0 = c_mul(m[KB][KB], inv);
     rowbuf[kt][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
@@ -156,7 +163,6 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
     if (tj == pl) {                                       // the winner publishes the pivot itself
         pivrec[kt].col = 16 * KB + pl;
         if (m[KB][KB].x == 0.0 && m[KB][KB].y == 0.0) atomicOr(weak, 2);      // singular: det = 0
-        permseq[16 * KB + trow] = 16 * KB + pl;          // row -> pivot column (the sign of this permutation enters c2)
         __asm__ volatile("" ::: "memory");
         __hip_atomic_store(&pivrec[kt].pad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -191,13 +197,13 @@ __device__ __forceinline__ bool pivot_step_valid(int kt, int nk) { return 4 * (k
 // every block.
 template <int NR, int KB, int RW, class Barrier>
 __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, int D, int seq,
-                                                cplx (*rowbuf)[RW], PivotRecord *pivrec, int *permseq, int *weak, int tid,
+                                                cplx (*rowbuf)[RW], PivotRecord *pivrec, int *weak, int tid,
                                                 Barrier &&barrier) {
     const int ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;
     const int nk = min(16, D - 16 * KB);
     bool live = 16 * KB + tj < D;
     barrier();
-    if (ti == 0) publish_pivot_row<NR, KB, RW>(m, det, live, 0, seq, rowbuf, pivrec, permseq, weak, tid);
+    if (ti == 0) publish_pivot_row<NR, KB, RW>(m, det, live, 0, seq, rowbuf, pivrec, weak, tid);
     for (int kt = 0; kt < 16; ++kt) {
         if (!pivot_step_valid(kt, nk)) continue;
         int next = kt + 1;
@@ -220,7 +226,7 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, in
         column_fetch<NR, KB>(m, c, pl);
 #pragma unroll
         for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
-        if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, det, live, next, seq, rowbuf, pivrec, permseq, weak, tid);
+        if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, det, live, next, seq, rowbuf, pivrec, weak, tid);
 #pragma unroll
         for (int ra = KB + 1; ra < NR; ++ra) {
 #pragma unroll
@@ -229,30 +235,32 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, in
     }
 }
 
-// The 16 row groups' partial pivot products -> detbuf[16] (call before the barrier that ends the elimination) ...
+// The 16 row groups' partial (signed) pivot products -> detbuf[16] (call before the barrier that ends the elimination) ...
 __device__ __forceinline__ void post_pivot_product(cplx det, cplx *detbuf, int tid) {
     if ((tid & 15) == 0) detbuf[tid >> 4] = det;
 }
-// ... and their product times the sign of the column permutation (one thread, after that barrier)
-__device__ __forceinline__ bool permutation_is_odd(const int *perm, int D);
-__device__ __forceinline__ cplx finish_determinant(const cplx *detbuf, const int *permseq, int D) {
+// ... and their product times the sign of the ROW order (one thread, after that barrier).  The signs of the column
+// choices are in the partial products already.
+__device__ __forceinline__ cplx finish_determinant(const cplx *detbuf, bool rows_odd) {
     cplx det = detbuf[0];
 #pragma unroll
     for (int g = 1; g < 16; ++g) det = c_mul(det, detbuf[g]);
-    return permutation_is_odd(permseq, D) ? c_make(-det.x, -det.y) : det;
+    return rows_odd ? c_make(-det.x, -det.y) : det;
 }
-
-// sign of the permutation row s -> perm[s], s < D <= 128 (cycle decomposition; one thread)
-__device__ __forceinline__ bool permutation_is_odd(const int *perm, int D) {
-    unsigned long long seen[2] = {0ull, 0ull};
-    int transpositions = 0;
-    for (int s = 0; s < D; ++s) {
-        if ((seen[s >> 6] >> (s & 63)) & 1ull) continue;
-        int len = 0, x = s;
-        while (!((seen[x >> 6] >> (x & 63)) & 1ull)) { seen[x >> 6] |= 1ull << (x & 63); x = perm[x]; ++len; }
-        transpositions += len - 1;
+// Sign of the order in which the rows are eliminated (pivot step kt of a block takes row 4 (kt & 3) + (kt >> 2), steps
+// beyond the last row are skipped): true if the sequence is an odd permutation of the natural order.  Depends on D
+// only -- evaluated once per kernel.
+__device__ __forceinline__ bool row_order_is_odd(int D) {
+    int inversions = 0;
+    for (int kb = 0; 16 * kb < D; ++kb) {
+        const int nk = min(16, D - 16 * kb);
+        for (int k1 = 0; k1 < 16; ++k1)
+            for (int k2 = k1 + 1; k2 < 16; ++k2) {
+                const int r1 = 4 * (k1 & 3) + (k1 >> 2), r2 = 4 * (k2 & 3) + (k2 >> 2);
+                if (r1 < nk && r2 < nk && r1 > r2) ++inversions;
+            }
     }
-    return (transpositions & 1) != 0;
+    return (inversions & 1) != 0;
 }
 
 }  // namespace

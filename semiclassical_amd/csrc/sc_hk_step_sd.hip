@@ -46,9 +46,10 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     __shared__ double scl[4 * 64];           // st, 1/st, si, 1/si
     __shared__ cplx rowbuf[16][64];
     __shared__ PivotRecord pivrec[16];
-    __shared__ int permseq[64];
-    __shared__ cplx detbuf[16];              // partial pivot products of the 16 row groups
-    __shared__ int weak;                     // bit 0: weak in-block pivot (-> pivoted fallback), bit 1: zero pivot
+    // per-trajectory results of the elimination, double-buffered by trajectory parity: thread 0 finishes trajectory t
+    // (product of the partial determinants, branch tracker) while the other waves already stream trajectory t+1
+    __shared__ cplx detbuf[2][16];           // signed partial pivot products of the 16 row groups
+    __shared__ int weakbuf[2];               // bit 0: weak in-block pivot (-> pivoted fallback), bit 1: zero pivot
 
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
     const int tj = tid & 15;
@@ -67,22 +68,23 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     }
     __syncthreads();
 
+    const bool rows_odd = row_order_is_odd(D);
+    const int pslot = (tid / D) * 64 + (tid % D);  // where this thread's element of st.work goes in prop
     int seq0 = 0;                                  // tags of this workgroup's pivot records: unique per (trajectory, block)
-    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += 4) {
+    int par = 0;
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += 4, par ^= 1) {
         double *M = A.st.mono + tr * 4 * (int64_t)DD;
+        int *weak = &weakbuf[par];
 #ifdef SC_TUNING
-        if (tid == 0) weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: tuning build, force the fallback (SC_DEBUG_FORCE_FIXUP)
+        if (tid == 0) *weak = (A.mode & 0x400) ? 1 : 0;    // 0x400: tuning build, force the fallback (SC_DEBUG_FORCE_FIXUP)
 #else
-        if (tid == 0) weak = 0;
+        if (tid == 0) *weak = 0;
 #endif
-
-        if (do_step) {
-            // row propagators P_a of this trajectory, computed by hk_modes_kernel ("phase A")
-            const double *pr = A.st.work + tr * 4 * (int64_t)D;
-            __syncthreads();
-            for (int i = tid; i < 4 * D; i += 256) prop[(i / D) * 64 + (i % D)] = pr[i];
-            __syncthreads();
-        }
+        // row propagators P_a of this trajectory, computed by hk_modes_kernel ("phase A"): the load is issued here, the
+        // values go to LDS once the first slot's loads are under way (every wave is past the previous trajectory's
+        // phase B -- the elimination barriers lie in between -- so prop may be overwritten without another barrier)
+        double prv = 0.0;
+        if (do_step && tid < 4 * D) prv = A.st.work[tr * 4 * (int64_t)D + tid];
 
         // ---------------- phase B ----------------
         // LDS indices derived from til / tjl are recomputed per trajectory: hipcc otherwise hoists them out of the
@@ -95,8 +97,6 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
             const int a = 16 * ra + til;
             const bool rowok = a < D;
             const int al = a & 63;
-            const double p11 = prop[al], p12 = prop[64 + al], p21 = prop[128 + al], p22 = prop[192 + al];
-            const double sta = scl[al], ista = scl[64 + al];
             double vqq[NR], vqp[NR], vpq[NR], vpp[NR];
             // rows / columns of tile (ra, rb); plane = distance between the four blocks of an element
             const int nra = min(16, D - 16 * ra);
@@ -108,11 +108,19 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                 const double *pe = M + __builtin_amdgcn_readfirstlane(TILED ? 4 * (16 * ra * D + nra * 16 * rb) : 16 * ra * D + 16 * rb);
                 const int plane = __builtin_amdgcn_readfirstlane(TILED ? nra * ncb : DD);
                 const unsigned to = (TILED && rb == NR - 1) ? toffl : toff;
+                // four scalar bases: every access is "SGPR pair + the thread's 32-bit offset"
+                const double *pe1 = pe + plane, *pe2 = pe1 + plane, *pe3 = pe2 + plane;
                 vqq[rb] = ok ? pe[to] : 0.0;
-                vqp[rb] = ok ? pe[plane + to] : 0.0;
-                vpq[rb] = ok ? pe[2 * plane + to] : 0.0;
-                vpp[rb] = ok ? pe[3 * plane + to] : 0.0;
+                vqp[rb] = ok ? pe1[to] : 0.0;
+                vpq[rb] = ok ? pe2[to] : 0.0;
+                vpp[rb] = ok ? pe3[to] : 0.0;
             }
+            if (do_step && ra == 0) {
+                if (tid < 4 * D) prop[pslot] = prv;
+                __syncthreads();
+            }
+            const double p11 = prop[al], p12 = prop[64 + al], p21 = prop[128 + al], p22 = prop[192 + al];
+            const double sta = scl[al], ista = scl[64 + al];
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
                 const int b = 16 * rb + tj;
@@ -126,7 +134,8 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                     const double nqq = fma(p12, mpq, p11 * mqq), npq = fma(p22, mpq, p21 * mqq);
                     const double nqp = fma(p12, mpp, p11 * mqp), npp = fma(p22, mpp, p21 * mqp);
                     mqq = nqq; mpq = npq; mqp = nqp; mpp = npp;
-                    if (ok) { pe[to] = mqq; pe[plane + to] = mqp; pe[2 * plane + to] = mpq; pe[3 * plane + to] = mpp; }
+                    double *pe1 = pe + plane, *pe2 = pe1 + plane, *pe3 = pe2 + plane;
+                    if (ok) { pe[to] = mqq; pe1[to] = mqp; pe2[to] = mpq; pe3[to] = mpp; }
                 }
                 const int bl = (16 * rb + tjl) & 63;
                 const double sib = scl[128 + bl], isib = scl[192 + bl];
@@ -145,18 +154,19 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
 #endif
         if (!skip_lu) {
             auto wg_barrier = [] { __syncthreads(); };
-            eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0), 64>(m, det, D, seq0 + 2, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0), 64>(m, det, D, seq0 + 3, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
-            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0), 64>(m, det, D, seq0 + 4, rowbuf, pivrec, permseq, &weak, tid, wg_barrier);
+            eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, weak, tid, wg_barrier);
+            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0), 64>(m, det, D, seq0 + 2, rowbuf, pivrec, weak, tid, wg_barrier);
+            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0), 64>(m, det, D, seq0 + 3, rowbuf, pivrec, weak, tid, wg_barrier);
+            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0), 64>(m, det, D, seq0 + 4, rowbuf, pivrec, weak, tid, wg_barrier);
         }
-        post_pivot_product(det, detbuf, tid);
+        post_pivot_product(det, detbuf[par], tid);
         __syncthreads();
-        if (tid == 0 && (weak & 1) && A.st.flags && !skip_lu) {
+        // no barrier after this: the buffers of this parity are next written two trajectories on
+        if (tid == 0 && (*weak & 1) && A.st.flags && !skip_lu) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
             atomicAdd(&A.st.flags[A.st.n], 1);   // lets the fix-up launch return at once when nothing was flagged
         } else if (tid == 0) {
-            const cplx c2new = (weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf, permseq, D);
+            const cplx c2new = (*weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf[par], rows_odd);
             cplx *c2 = (cplx *)A.st.c2;
             if (do_step) {
                 const cplx prev = c2[tr];
@@ -166,7 +176,6 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
             }
             c2[tr] = c2new;
         }
-        __syncthreads();
     }
 }
 

@@ -40,7 +40,6 @@ struct WsLds {
     double scl[4 * 64];                       // st, 1/st, si, 1/si
     cplx rowbuf[WS_GROUPS][16][64];
     PivotRecord pivrec[WS_GROUPS][16];
-    int permseq[WS_GROUPS][64];
     int weak[WS_GROUPS];
     cplx detbuf[WS_GROUPS][16];
     int bar[WS_GROUPS];                       // monotonic arrival counters of the group barriers
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
     const int g = role - 1;
     cplx (*rowbuf)[64] = S.rowbuf[g];
     PivotRecord *pivrec = S.pivrec[g];
-    int *permseq = S.permseq[g], *weak = &S.weak[g];
+    int *weak = &S.weak[g];
     cplx *detbuf = S.detbuf[g];
     int bar_target = 0, seq0 = 0;
     auto barrier = [&] { group_barrier(&S.bar[g], bar_target, lane, &S.err); };
@@ -204,10 +203,10 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
 
         cplx det = c_make(1.0, 0.0);
 #ifndef WS_ABLATE_LU
-        eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 1, 64>(m, det, D, seq0 + 2, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 2, 64>(m, det, D, seq0 + 3, rowbuf, pivrec, permseq, weak, ltid, barrier);
-        eliminate_block<NR, 3, 64>(m, det, D, seq0 + 4, rowbuf, pivrec, permseq, weak, ltid, barrier);
+        eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, weak, ltid, barrier);
+        eliminate_block<NR, 1, 64>(m, det, D, seq0 + 2, rowbuf, pivrec, weak, ltid, barrier);
+        eliminate_block<NR, 2, 64>(m, det, D, seq0 + 3, rowbuf, pivrec, weak, ltid, barrier);
+        eliminate_block<NR, 3, 64>(m, det, D, seq0 + 4, rowbuf, pivrec, weak, ltid, barrier);
 #else
         det = m[0][0];
 #endif
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
                 A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
                 atomicAdd(&A.st.flags[A.st.n], 1);
             } else {
-                det = (*weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf, permseq, D);
+                det = (*weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf, row_order_is_odd(D));
                 const cplx prev = c2[tr];
                 if (prev.x < 0.0 && det.x < 0.0 && prev.y * det.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
                 c2[tr] = det;
