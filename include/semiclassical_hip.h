@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        8
+#define SC_ABI_VERSION        9
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -88,9 +88,10 @@ typedef struct sc_state {
     double *c2;
     double *sgn;
     double *work;           /* [n][4][D] scratch of the separable fast path: RK4 propagators of the monodromy rows */
-    int32_t *flags;         /* [n + 1], zero-initialised scratch: flags[i] != 0 marks a trajectory whose determinant
+    int32_t *flags;         /* [n + 2], zero-initialised scratch: flags[i] != 0 marks a trajectory whose determinant
                                the fast path hands to the fully pivoted elimination, flags[n] counts them for the
-                               current step (may be NULL) */
+                               current step, flags[n + 1] is the cursor through which the fast kernel hands out
+                               trajectories to its workgroups (may be NULL: no fallback, static assignment) */
 } sc_state;
 
 /* constants of the HK prefactor, reference propagators.py:951-1004.

@@ -73,7 +73,7 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 8              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 9              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 

@@ -403,11 +403,11 @@ __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
 // The LDS kernel above needs 16 d'^2 bytes per trajectory (one workgroup per CU at D = 90) and two barriers per pivot:
 // 10 ms at D = 90, n = 1e4.  Trajectories whose in-block pivot is too weak are flagged and redone by the LDS kernel.
 template <int NR, int KB, int RW, class Barrier>
-__device__ __forceinline__ void eliminate_all_blocks(cplx (&m)[NR][NR], cplx &det, int D, int seq0, cplx (*rowbuf)[RW],
+__device__ __forceinline__ void eliminate_all_blocks(cplx (&m)[NR][NR], cplx *detbuf, int D, int seq0, cplx (*rowbuf)[RW],
                                                      PivotRecord *pivrec, int *weak, int tid, Barrier &&barrier) {
     if constexpr (KB < NR) {
-        eliminate_block<NR, KB, RW>(m, det, D, seq0 + 1 + KB, rowbuf, pivrec, weak, tid, barrier);
-        eliminate_all_blocks<NR, KB + 1, RW>(m, det, D, seq0, rowbuf, pivrec, weak, tid, barrier);
+        eliminate_block<NR, KB, RW>(m, detbuf, D, seq0 + 1 + KB, rowbuf, pivrec, weak, tid, barrier);
+        eliminate_all_blocks<NR, KB + 1, RW>(m, detbuf, D, seq0, rowbuf, pivrec, weak, tid, barrier);
     }
 }
 
@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
     for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += NR) {
         const double *M = A.st.mono + tr * 4 * (int64_t)DD;
         if (tid == 0) weak = 0;
+        if (tid < 16) detbuf[tid] = c_make(1.0, 0.0);
         int til = trow, tjl = tj;
         __asm__ volatile("" : "+v"(til), "+v"(tjl));            // LDS indices recomputed per trajectory, not hoisted and spilled
         cplx m[NR][NR];
@@ -460,16 +461,14 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
                 __asm__ volatile("" : "+v"(m[ra][rb].x), "+v"(m[ra][rb].y) : : "memory");
             }
         }
-        cplx det = c_make(1.0, 0.0);
-        eliminate_all_blocks<NR, 0, RW>(m, det, D, seq0, rowbuf, pivrec, &weak, tid, barrier);
-        post_pivot_product(det, detbuf, tid);
+        eliminate_all_blocks<NR, 0, RW>(m, detbuf, D, seq0, rowbuf, pivrec, &weak, tid, barrier);
         __syncthreads();
         if (tid == 0) {
             if (weak) {
                 A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted LDS elimination
                 atomicAdd(&A.st.flags[A.st.n], 1);
             } else {
-                det = finish_determinant(detbuf, rows_odd);
+                const cplx det = finish_determinant(detbuf, rows_odd);
                 cplx *c2 = (cplx *)A.st.c2;
                 if (A.mode == 0) {
                     const cplx prev = c2[tr];

@@ -130,11 +130,12 @@ __device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[
 // The 16 lanes that own row k = 16*KB + kt pick the pivot column among the live columns of the diagonal block,
 // scale the row by 1/pivot and publish it: row -> rowbuf[kt], pivot -> pivrec[kt], and LAST the record's tag
 // (= seq), which the consumers poll.  LDS operations of one wave execute in issue order, so a consumer that sees
-// the tag sees the row.  Runs inside `if (ti == kt)`: only the 16 owner lanes multiply the pivot into their `det`
-// (every row group accumulates the pivots of its own rows, the caller multiplies the 16 partial products at the end)
-// and a zero pivot sets bit 1 of *weak -- the consumers carry neither the determinant nor a singularity flag.
+// the tag sees the row.  Runs inside `if (ti == kt)`.  The winner lane multiplies the (signed) pivot into detbuf[row
+// group] in LDS -- every row group accumulates the pivots of its own rows, one thread multiplies the 16 partial products
+// at the end -- and a zero pivot sets bit 1 of *weak: no thread carries the determinant or a singularity flag in
+// registers.  detbuf[0..16) must hold 1 before the first block starts.
 template <int NR, int KB, int RW>
-__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx &det, bool live, int kt, int seq,
+__device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx *detbuf, bool live, int kt, int seq,
                                                   cplx (*rowbuf)[RW], PivotRecord *pivrec, int *weak, int tid) {
     const int tj = tid & 15, lane = tid & 63;
     // key = upper 26 bits of |a_kj|^2 (as an integer) | (15 - tj)
@@ -150,11 +151,6 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
     // 16 owner lanes are active, so the ballot holds exactly their `live` bits) = p adjacent transpositions
     const unsigned long long lm = __ballot(live);
     const int flip = (__popcll(lm & ((1ull << src) - 1ull)) & 1) << 31;
-    const cplx piv = c_make(__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m[KB][KB].x), src) ^ flip,
-                                             __builtin_amdgcn_readlane(__double2loint(m[KB][KB].x), src)),
-                            __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m[KB][KB].y), src) ^ flip,
-                                             __builtin_amdgcn_readlane(__double2loint(m[KB][KB].y), src)));
-    det = c_mul(det, piv);
     const bool keep = live && tj != pl;
     const cplx r0 = c_mul(m[KB][KB], inv);
     rowbuf[kt][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
@@ -163,6 +159,9 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
     if (tj == pl) {                                       // the winner publishes the pivot itself
         pivrec[kt].col = 16 * KB + pl;
         if (m[KB][KB].x == 0.0 && m[KB][KB].y == 0.0) atomicOr(weak, 2);      // singular: det = 0
+        const cplx piv = c_make(__hiloint2double(__double2hiint(m[KB][KB].x) ^ flip, __double2loint(m[KB][KB].x)),
+                                __hiloint2double(__double2hiint(m[KB][KB].y) ^ flip, __double2loint(m[KB][KB].y)));
+        detbuf[tid >> 4] = c_mul(detbuf[tid >> 4], piv);
         __asm__ volatile("" ::: "memory");
         __hip_atomic_store(&pivrec[kt].pad, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -193,17 +192,16 @@ __device__ __forceinline__ bool pivot_step_valid(int kt, int nk) { return 4 * (k
 
 // `tid` = index of the thread inside its 256-thread elimination group (= threadIdx.x when the group is the workgroup),
 // `barrier()` synchronises the four wavefronts of the group.
-// `det`: this thread's partial product of pivots (see publish_pivot_row); start it at 1 and hand the same variable to
-// every block.
+// `detbuf`: the 16 partial products of pivots in LDS (see publish_pivot_row), all 1 before block 0.
 template <int NR, int KB, int RW, class Barrier>
-__device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, int D, int seq,
+__device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx *detbuf, int D, int seq,
                                                 cplx (*rowbuf)[RW], PivotRecord *pivrec, int *weak, int tid,
                                                 Barrier &&barrier) {
     const int ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;
     const int nk = min(16, D - 16 * KB);
     bool live = 16 * KB + tj < D;
     barrier();
-    if (ti == 0) publish_pivot_row<NR, KB, RW>(m, det, live, 0, seq, rowbuf, pivrec, weak, tid);
+    if (ti == 0) publish_pivot_row<NR, KB, RW>(m, detbuf, live, 0, seq, rowbuf, pivrec, weak, tid);
     for (int kt = 0; kt < 16; ++kt) {
         if (!pivot_step_valid(kt, nk)) continue;
         int next = kt + 1;
@@ -226,7 +224,7 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, in
         column_fetch<NR, KB>(m, c, pl);
 #pragma unroll
         for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
-        if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, det, live, next, seq, rowbuf, pivrec, weak, tid);
+        if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, detbuf, live, next, seq, rowbuf, pivrec, weak, tid);
 #pragma unroll
         for (int ra = KB + 1; ra < NR; ++ra) {
 #pragma unroll
@@ -235,12 +233,8 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx &det, in
     }
 }
 
-// The 16 row groups' partial (signed) pivot products -> detbuf[16] (call before the barrier that ends the elimination) ...
-__device__ __forceinline__ void post_pivot_product(cplx det, cplx *detbuf, int tid) {
-    if ((tid & 15) == 0) detbuf[tid >> 4] = det;
-}
-// ... and their product times the sign of the ROW order (one thread, after that barrier).  The signs of the column
-// choices are in the partial products already.
+// The product of the 16 row groups' partial (signed) pivot products times the sign of the ROW order (one thread, after
+// the barrier that ends the elimination).  The signs of the column choices are in the partial products already.
 __device__ __forceinline__ cplx finish_determinant(const cplx *detbuf, bool rows_odd) {
     cplx det = detbuf[0];
 #pragma unroll

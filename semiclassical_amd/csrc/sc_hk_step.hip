@@ -275,7 +275,8 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
         const char *which = getenv("SC_FAST_KERNEL");
         if (which && which[0] == 'r') return sc_launch_step_rw(a, (hipStream_t)stream);
 #endif
-        if (st->flags && hipMemsetAsync(st->flags + st->n, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
+        // flags[n]: trajectories flagged in this step, flags[n + 1]: trajectory cursor of the fast kernel
+        if (st->flags && hipMemsetAsync(st->flags + st->n, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
             return sc_check_launch("sc_hk_step (flag counter)");
         const int rc = sc_launch_step_sd(a, (hipStream_t)stream);
         if (rc != SC_OK || !st->flags || (dbg & 0x100)) return rc;

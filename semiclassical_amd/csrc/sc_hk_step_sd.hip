@@ -30,10 +30,24 @@
 //            LDS elimination of sc_hk_step.hip in the same stream (never observed for HK matrices so far; the
 //            path is exercised by tests/test_hk_gpu.py::test_weak_pivot_fallback).
 //            Then the sqrt branch tracker.                   (torch.det, propagators.py:999, 1006-1052)
+#include <algorithm>
 #include "sc_common.h"
 #include "sc_hk_lu.h"
+#include "sc_row16.h"
+
+#ifndef SC_SD_DEPTH
+#define SC_SD_DEPTH 1      // row slots whose loads are in flight together (1: the schedule up to round 2)
+#endif
+#ifndef SC_SD_XPREFETCH
+#define SC_SD_XPREFETCH 1  // request row slot 0 of the next trajectory before the last diagonal block of the elimination
+#endif
+#ifndef SC_SD_BLOCK_BARRIER
+#define SC_SD_BLOCK_BARRIER no_barrier     // wg_barrier: a workgroup barrier in front of every diagonal block
+#endif
 
 namespace {
+
+typedef unsigned int sc_v2u __attribute__((ext_vector_type(2)));
 
 // TILED: the monodromy blocks of a trajectory are stored as 16 x 16 tiles (sc_state.mono_layout = 1, see the header):
 // tile (ra, rb) holds its part of Mqq, Mqp, Mpq, Mpp one after the other, each row-major inside the tile.  With the
@@ -50,15 +64,11 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     // (product of the partial determinants, branch tracker) while the other waves already stream trajectory t+1
     __shared__ cplx detbuf[2][16];           // signed partial pivot products of the 16 row groups
     __shared__ int weakbuf[2];               // bit 0: weak in-block pivot (-> pivoted fallback), bit 1: zero pivot
+    __shared__ int nextbuf[2];               // what thread 0 drew from the trajectory cursor
 
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
-    const int tj = tid & 15;
-    const int trow = (tid >> 6) * 4 + ((tid >> 4) & 3);     // wave w holds rows 4w .. 4w+3 of every 16-row slot
     constexpr bool do_step = STEP;                   // false: prefactor and tracker initialisation only (t = 0)
     constexpr int NCL_BASE = 16 * (NR - 1);          // first column of the last column tile
-    // per-thread element offsets: row-major (trow, tj) of a D x D plane; tiled: inside a 16-wide / the last tile
-    const unsigned toff = TILED ? (unsigned)(trow * 16 + tj) : (unsigned)(trow * D + tj);
-    const unsigned toffl = (unsigned)(trow * (D - NCL_BASE) + tj);
     if (tid < 64) {
         const bool in = tid < D;
         const double st = in ? A.hk.st[tid] : 1.0, si = in ? A.hk.si[tid] : 1.0;
@@ -69,103 +79,187 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     __syncthreads();
 
     const bool rows_odd = row_order_is_odd(D);
-    const int pslot = (tid / D) * 64 + (tid % D);  // where this thread's element of st.work goes in prop
+    // the thread index is rebuilt per trajectory from the wave number (a scalar) and the lane number (v_mbcnt): no
+    // thread-index register lives across the elimination
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
     int seq0 = 0;                                  // tags of this workgroup's pivot records: unique per (trajectory, block)
     int par = 0;
-    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += 4, par ^= 1) {
-        double *M = A.st.mono + tr * 4 * (int64_t)DD;
+    // raw[s][p][rb]: the four planes (Mqq, Mqp, Mpq, Mpp) of row slot ra = s (mod 2); prv: this thread's element of the
+    // row propagators P_a (st.work, computed by hk_modes_kernel, "phase A").  With SC_SD_XPREFETCH slot 0 and prv of the
+    // NEXT trajectory are requested before the last diagonal block of the current elimination starts (most of the matrix
+    // registers are dead by then): the first load round trip of a trajectory hides behind that block.
+    double raw[2][4][NR];
+    double prv = 0.0;
+    bool first = true;
+    // Trajectories are handed out through a device-side cursor (sc_state.flags[n + 1], zeroed by sc_hk_step): the first
+    // gridDim.x statically, every further one to whichever workgroup is ready next.  The trajectories in flight are then
+    // always ~gridDim.x CONSECUTIVE ones (static strides let the workgroups drift apart until the accesses are spread over
+    // the whole state: measured 5.3 ms against 4.8 ms for compact windows), and nobody waits for a slow workgroup at the
+    // end.  Thread 0 draws the next index at the top of a trajectory; it reaches the others through LDS behind the first
+    // barrier of the elimination.  Without sc_state.flags: static stride.
+    int *cursor = A.st.flags ? A.st.flags + A.st.n + 1 : nullptr;
+    int64_t trn = 0;
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr = trn, seq0 += 4, par ^= 1) {
         int *weak = &weakbuf[par];
+        // Everything derived from the thread index is recomputed per trajectory: hipcc otherwise keeps those values live
+        // across the elimination, spills them, and reloads them one by one behind s_waitcnt vmcnt(0) in the load stream
+        unsigned ones = ~0u;
+        __asm__ volatile("" : "+s"(ones));
+        const int tl = (wave_s << 6) | (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        const int tj = tl & 15, tjl = tj;
+        const int til = (tl >> 6) * 4 + ((tl >> 4) & 3);    // wave w holds rows 4w .. 4w+3 of every 16-row slot
 #ifdef SC_TUNING
-        if (tid == 0) *weak = (A.mode & 0x400) ? 1 : 0;    // 0x400: tuning build, force the fallback (SC_DEBUG_FORCE_FIXUP)
+        if (tl == 0) *weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: tuning build, force the fallback (SC_DEBUG_FORCE_FIXUP)
 #else
-        if (tid == 0) *weak = 0;
+        if (tl == 0) *weak = 0;
 #endif
-        // row propagators P_a of this trajectory, computed by hk_modes_kernel ("phase A"): the load is issued here, the
-        // values go to LDS once the first slot's loads are under way (every wave is past the previous trajectory's
-        // phase B -- the elimination barriers lie in between -- so prop may be overwritten without another barrier)
-        double prv = 0.0;
-        if (do_step && tid < 4 * D) prv = A.st.work[tr * 4 * (int64_t)D + tid];
+        if (tl < 16) detbuf[par][tl] = c_make(1.0, 0.0);
+        int drawn = 0;
+        if (cursor && tl == 0) drawn = atomicAdd(cursor, 1);
+        const int pk = tl >> 6, pa = tl & 63;               // thread -> (row of P, mode) of st.work
 
         // ---------------- phase B ----------------
-        // LDS indices derived from til / tjl are recomputed per trajectory: hipcc otherwise hoists them out of the
-        // trajectory loop, spills them, and reloads them one by one behind s_waitcnt vmcnt(0) in the middle of the stream
-        int til = trow, tjl = tj;
-        __asm__ volatile("" : "+v"(til), "+v"(tjl));
         cplx m[NR][NR];
-#pragma unroll
-        for (int ra = 0; ra < NR; ++ra) {
-            const int a = 16 * ra + til;
-            const bool rowok = a < D;
-            const int al = a & 63;
-            double vqq[NR], vqp[NR], vpq[NR], vpp[NR];
-            // rows / columns of tile (ra, rb); plane = distance between the four blocks of an element
-            const int nra = min(16, D - 16 * ra);
+        // All accesses to the trajectory's blocks are raw BUFFER instructions: one resource (base M, 32 D^2 bytes), the
+        // tile / plane position as scalar byte offset, the thread's position inside the tile as 32-bit VGPR offset.
+        // Threads outside the matrix carry an offset beyond the resource: their loads return 0 and their stores are
+        // dropped by the range check, so phase B has no branches and no 64-bit address arithmetic.
+        int Dl = D;
+        __asm__ volatile("" : "+s"(Dl));                 // tile offsets are recomputed (SALU) per trajectory, not kept in SGPRs
+        constexpr unsigned OOB = 0x7fffffffu;
+        const bool rowok_last = 16 * (NR - 1) + til < Dl, colok_last = NCL_BASE + tj < Dl;
+        // byte offsets of this thread inside a tile: row-major (row, tj) of a D x D plane; tiled: inside a 16-wide / the
+        // last (narrower) column tile
+        const unsigned vo = 8u * (TILED ? (unsigned)(til * 16 + tj) : (unsigned)(til * Dl + tj));
+        const unsigned vol = TILED ? 8u * (unsigned)(til * (Dl - NCL_BASE) + tj) : vo;
+        auto voffset = [&](int ra, int rb) {
+            const unsigned v = rb == NR - 1 ? vol : vo;
+            const bool ok = (ra < NR - 1 || rowok_last) && (rb < NR - 1 || colok_last);
+            return (int)((ra < NR - 1 && rb < NR - 1) ? v : (ok ? v : OOB));
+        };
+        auto tile_base = [&](int ra, int rb) {           // scalar byte offset of tile (ra, rb)
+            const int nra = min(16, Dl - 16 * ra);
+            return 8 * (TILED ? 4 * (16 * ra * Dl + nra * 16 * rb) : 16 * ra * Dl + 16 * rb);
+        };
+        auto plane_bytes = [&](int ra, int rb) {         // distance between the four blocks of an element
+            const int nra = min(16, Dl - 16 * ra), ncb = rb == NR - 1 ? Dl - NCL_BASE : 16;
+            return 8 * (TILED ? nra * ncb : Dl * Dl);
+        };
+        auto resource = [&](int64_t t) {
+            return __builtin_amdgcn_make_buffer_rsrc(A.st.mono + t * 4 * (int64_t)Dl * Dl, 0, 32 * Dl * Dl, 0x00020000);
+        };
+        auto load_slot = [&](auto rac, int64_t t) {
+            constexpr int ra = decltype(rac)::value;
+            const __amdgpu_buffer_rsrc_t rs = resource(t);
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
-                const bool ok = rowok && 16 * rb + tj < D;
-                // wave-uniform element base (scalar registers) + one per-thread 32-bit offset
-                const int ncb = rb == NR - 1 ? D - NCL_BASE : 16;
-                const double *pe = M + __builtin_amdgcn_readfirstlane(TILED ? 4 * (16 * ra * D + nra * 16 * rb) : 16 * ra * D + 16 * rb);
-                const int plane = __builtin_amdgcn_readfirstlane(TILED ? nra * ncb : DD);
-                const unsigned to = (TILED && rb == NR - 1) ? toffl : toff;
-                // four scalar bases: every access is "SGPR pair + the thread's 32-bit offset"
-                const double *pe1 = pe + plane, *pe2 = pe1 + plane, *pe3 = pe2 + plane;
-                vqq[rb] = ok ? pe[to] : 0.0;
-                vqp[rb] = ok ? pe1[to] : 0.0;
-                vpq[rb] = ok ? pe2[to] : 0.0;
-                vpp[rb] = ok ? pe3[to] : 0.0;
+                const int vofs = voffset(ra, rb), base = tile_base(ra, rb), plane = plane_bytes(ra, rb);
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) {
+                    const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, vofs, base + pl * plane, 0);
+                    raw[ra & 1][pl][rb] = __hiloint2double((int)v.y, (int)v.x);
+                }
             }
-            if (do_step && ra == 0) {
-                if (tid < 4 * D) prop[pslot] = prv;
-                __syncthreads();
-            }
+        };
+        auto first_requests = [&](int64_t t) {           // P_a and row slot 0 of trajectory t
+            if (do_step && pa < Dl) prv = A.st.work[(t * 4 + pk) * (int64_t)Dl + pa];
+            load_slot(std::integral_constant<int, 0>(), t);
+        };
+        auto finish_slot = [&](auto rac) {
+            constexpr int ra = decltype(rac)::value;
+            const __amdgpu_buffer_rsrc_t rs = resource(tr);
+            const int al = (16 * ra + til) & 63;
             const double p11 = prop[al], p12 = prop[64 + al], p21 = prop[128 + al], p22 = prop[192 + al];
             const double sta = scl[al], ista = scl[64 + al];
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
-                const int b = 16 * rb + tj;
-                const bool ok = rowok && b < D;
-                const int ncb = rb == NR - 1 ? D - NCL_BASE : 16;
-                double *pe = M + __builtin_amdgcn_readfirstlane(TILED ? 4 * (16 * ra * D + nra * 16 * rb) : 16 * ra * D + 16 * rb);
-                const int plane = __builtin_amdgcn_readfirstlane(TILED ? nra * ncb : DD);
-                const unsigned to = (TILED && rb == NR - 1) ? toffl : toff;
-                double mqq = vqq[rb], mqp = vqp[rb], mpq = vpq[rb], mpp = vpp[rb];
+                const int vofs = voffset(ra, rb), base = tile_base(ra, rb), plane = plane_bytes(ra, rb);
+                double mqq = raw[ra & 1][0][rb], mqp = raw[ra & 1][1][rb], mpq = raw[ra & 1][2][rb], mpp = raw[ra & 1][3][rb];
                 if (do_step) {
                     const double nqq = fma(p12, mpq, p11 * mqq), npq = fma(p22, mpq, p21 * mqq);
                     const double nqp = fma(p12, mpp, p11 * mqp), npp = fma(p22, mpp, p21 * mqp);
                     mqq = nqq; mpq = npq; mqp = nqp; mpp = npp;
-                    double *pe1 = pe + plane, *pe2 = pe1 + plane, *pe3 = pe2 + plane;
-                    if (ok) { pe[to] = mqq; pe1[to] = mqp; pe2[to] = mpq; pe3[to] = mpp; }
+                    const double out[4] = {mqq, mqp, mpq, mpp};
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) {
+                        sc_v2u v;
+                        v.x = (unsigned)__double2loint(out[pl]); v.y = (unsigned)__double2hiint(out[pl]);
+                        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vofs, base + pl * plane, 0);
+                    }
                 }
                 const int bl = (16 * rb + tjl) & 63;
                 const double sib = scl[128 + bl], isib = scl[192 + bl];
-                m[ra][rb] = ok ? c_make(0.5 * (sta * isib * mqq + ista * sib * mpp),
-                                        0.5 * (-SC_HBAR * sta * sib * mqp + (1.0 / SC_HBAR) * ista * isib * mpq))
-                               : c_make(0.0, 0.0);
+                // elements outside the matrix were loaded as zeros: their mat entries are zeros
+                m[ra][rb] = c_make(0.5 * (sta * isib * mqq + ista * sib * mpp),
+                                   0.5 * (-SC_HBAR * sta * sib * mqp + (1.0 / SC_HBAR) * ista * isib * mpq));
+                // the element must exist HERE: hipcc otherwise sinks its computation to the first use in the elimination
+                // and carries (spills) the four raw values and the scalings instead
+                __asm__ volatile("" : "+v"(m[ra][rb].x), "+v"(m[ra][rb].y));
             }
+        };
+        // sched_barrier: the stages are scheduled one by one (hipcc otherwise interleaves the stages of this branch-free
+        // block until the raw values of three slots are live at once, and spills)
+        if (first || !SC_SD_XPREFETCH || NR == 1) first_requests(tr);
+        first = false;
+        __builtin_amdgcn_sched_barrier(0);
+        if (NR > 1 && SC_SD_DEPTH > 1) load_slot(std::integral_constant<int, (NR > 1 ? 1 : 0)>(), tr);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_step) {
+            // every wave is past the previous trajectory's phase B (the elimination barriers lie in between), so prop
+            // may be overwritten without another barrier
+            if (pa < D) prop[64 * pk + pa] = prv;
+            __syncthreads();
         }
+        sfor<0, NR>([&](auto rac) {
+            constexpr int ra = decltype(rac)::value;
+            if (SC_SD_DEPTH == 1 && ra > 0) load_slot(rac, tr);
+            if (SC_SD_DEPTH > 1 && ra + 1 < NR && ra > 0) load_slot(std::integral_constant<int, (ra + 1 < NR ? ra + 1 : 0)>(), tr);
+            __builtin_amdgcn_sched_barrier(0);
+            finish_slot(rac);
+            __builtin_amdgcn_sched_barrier(0);
+        });
 
         // ---------------- phase C: determinant in registers ----------------
-        cplx det = c_make(1.0, 0.0);             // this row group's share of the product of pivots
 #ifdef SC_TUNING
         const bool skip_lu = (A.mode & 0x100) != 0;      // tuning build only: phase ablation (SC_DEBUG_SKIP_LU)
 #else
         constexpr bool skip_lu = false;
 #endif
-        if (!skip_lu) {
-            auto wg_barrier = [] { __syncthreads(); };
-            eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, weak, tid, wg_barrier);
-            if (NR > 1) eliminate_block<NR, (NR > 1 ? 1 : 0), 64>(m, det, D, seq0 + 2, rowbuf, pivrec, weak, tid, wg_barrier);
-            if (NR > 2) eliminate_block<NR, (NR > 2 ? 2 : 0), 64>(m, det, D, seq0 + 3, rowbuf, pivrec, weak, tid, wg_barrier);
-            if (NR > 3) eliminate_block<NR, (NR > 3 ? 3 : 0), 64>(m, det, D, seq0 + 4, rowbuf, pivrec, weak, tid, wg_barrier);
-        }
-        post_pivot_product(det, detbuf[par], tid);
+        if (cursor && tl == 0) nextbuf[par] = drawn;
+        // Only block 0 starts behind a barrier (it also orders the resets above).  Later blocks need none: a wave
+        // owns every fourth pivot step, so when step s is published every wave has consumed step s - 4, and a row
+        // buffer is rewritten 16 steps after its last use.
+        auto wg_barrier = [] { __syncthreads(); };
+        auto no_barrier = [] {};
+        (void)no_barrier;
+        sfor<0, NR>([&](auto kbc) {
+            constexpr int KB = decltype(kbc)::value;
+            if (KB == (NR > 1 ? 1 : 0)) {            // behind the barrier of block 0 (NR = 1: the value is read after the last barrier)
+                if (NR > 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
+            }
+            if (SC_SD_XPREFETCH && NR > 1 && KB == NR - 1) {
+                if (trn < A.st.n) {
+                    first_requests(trn);
+                } else {                            // nothing follows: end the live ranges of the old values
+                    prv = 0.0;
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+                        for (int rb = 0; rb < NR; ++rb) raw[0][pl][rb] = 0.0;
+                }
+            }
+            if (!skip_lu) {
+                if (KB == 0) eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, wg_barrier);
+                else eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, SC_SD_BLOCK_BARRIER);
+            }
+        });
         __syncthreads();
+        if (NR == 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
         // no barrier after this: the buffers of this parity are next written two trajectories on
-        if (tid == 0 && (*weak & 1) && A.st.flags && !skip_lu) {
+        if (tl == 0 && (*weak & 1) && A.st.flags && !skip_lu) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
             atomicAdd(&A.st.flags[A.st.n], 1);   // lets the fix-up launch return at once when nothing was flagged
-        } else if (tid == 0) {
+        } else if (tl == 0) {
             const cplx c2new = (*weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf[par], rows_odd);
             cplx *c2 = (cplx *)A.st.c2;
             if (do_step) {
@@ -414,12 +508,16 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     // latency, so giving them a CU of their own does not help.
     if (nr == 4 && step && a.mode == 0 && getenv("SC_WS")) return sc_launch_step_ws(a, s);
 #endif
+    int sdgrid = grid;         // the energy partials belong to hk_modes_kernel: this kernel's grid is free
+#ifdef SC_TUNING
+    if (const char *g = getenv("SC_SD_GRID")) sdgrid = (int)std::min<int64_t>(a.st.n, atoi(g));
+#endif
 #define SC_LAUNCH_SD(NR_, OCC_)                                                                                         \
     do {                                                                                                                \
-        if (step && tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, true>), dim3(grid), dim3(256), 0, s, a);   \
-        else if (step) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, false>), dim3(grid), dim3(256), 0, s, a);     \
-        else if (tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, true>), dim3(grid), dim3(256), 0, s, a);    \
-        else hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, false>), dim3(grid), dim3(256), 0, s, a);              \
+        if (step && tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, true>), dim3(sdgrid), dim3(256), 0, s, a);   \
+        else if (step) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, false>), dim3(sdgrid), dim3(256), 0, s, a);     \
+        else if (tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, true>), dim3(sdgrid), dim3(256), 0, s, a);    \
+        else hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, false>), dim3(sdgrid), dim3(256), 0, s, a);              \
     } while (0)
     switch (nr) {
         case 1: SC_LAUNCH_SD(1, 4); break;

@@ -135,7 +135,7 @@ class HermanKlukPropagator(object):
         self._mono[:, 3] = eye
         self._c2 = torch.ones(n, dtype=C128, device=dev)
         self._sgn = torch.ones(n, dtype=F64, device=dev)
-        self._flags = torch.zeros(n + 1, dtype=torch.int32, device=dev)     # [n] = flagged count
+        self._flags = torch.zeros(n + 2, dtype=torch.int32, device=dev)     # [n] = flagged count, [n + 1] = work cursor
         self._work = torch.zeros((n, 4, d), dtype=F64, device=dev)
         self._state = sc_state(n=n, dim=d, mono_layout=_lib.SC_MONO_ROWMAJOR, qp=ptr(self._qp), act=ptr(self._act),
                                mono=ptr(self._mono), c2=ptr(self._c2), sgn=ptr(self._sgn), work=ptr(self._work),

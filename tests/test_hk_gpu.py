@@ -190,8 +190,8 @@ def test_dense_monodromy_through_fast_path():
     for name in ("hk_as60", "hk_as5_chi002"):
         got, want, prop = _prefactor_of_state(name, blocks)
         assert np.max(np.abs(got - want) / np.abs(want)) < 1e-10
-        assert int(prop._flags[:-1].sum().item()) == 0         # flags of handed-over trajectories are cleared again
-        assert int(prop._flags[-1].item()) < prop.ntraj        # the register elimination kept some of them
+        assert int(prop._flags[:-2].sum().item()) == 0         # flags of handed-over trajectories are cleared again
+        assert int(prop._flags[-2].item()) < prop.ntraj        # the register elimination kept some of them
 
 
 def test_weak_pivot_fallback():
@@ -205,8 +205,8 @@ def test_weak_pivot_fallback():
     got, want, prop = _prefactor_of_state("hk_as60", blocks)
     assert np.all(np.abs(want) > 0)
     assert np.max(np.abs(got - want) / np.abs(want)) < 1e-10
-    assert int(prop._flags[:-1].sum().item()) == 0             # flags cleared by the fix-up pass ...
-    assert int(prop._flags[-1].item()) == prop.ntraj           # ... which was needed for every trajectory
+    assert int(prop._flags[:-2].sum().item()) == 0             # flags cleared by the fix-up pass ...
+    assert int(prop._flags[-2].item()) == prop.ntraj           # ... which was needed for every trajectory
 
 
 def test_unsupported_sizes_fail_loudly():

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
     int k = g;
     for (int64_t tr = blockIdx.x + (int64_t)g * gridDim.x; tr < n; tr += (int64_t)WS_GROUPS * gridDim.x, k += WS_GROUPS, seq0 += 4) {
         if (ltid == 0) *weak = 0;
+        if (ltid < 16) detbuf[ltid] = c_make(1.0, 0.0);
         // take matrix k from the slot
         const bool arrived = wait_for(&S.full[w], k + 1);
         cplx m[NR][NR];
@@ -201,16 +202,15 @@ __global__ __launch_bounds__(1024, 1) void hk_step_ws_kernel(StepArgs A) {
         }
         __asm__ volatile("" ::: "memory");
 
-        cplx det = c_make(1.0, 0.0);
+        cplx det;
 #ifndef WS_ABLATE_LU
-        eliminate_block<NR, 0, 64>(m, det, D, seq0 + 1, rowbuf, pivrec, weak, ltid, barrier);
-        eliminate_block<NR, 1, 64>(m, det, D, seq0 + 2, rowbuf, pivrec, weak, ltid, barrier);
-        eliminate_block<NR, 2, 64>(m, det, D, seq0 + 3, rowbuf, pivrec, weak, ltid, barrier);
-        eliminate_block<NR, 3, 64>(m, det, D, seq0 + 4, rowbuf, pivrec, weak, ltid, barrier);
+        eliminate_block<NR, 0, 64>(m, detbuf, D, seq0 + 1, rowbuf, pivrec, weak, ltid, barrier);
+        eliminate_block<NR, 1, 64>(m, detbuf, D, seq0 + 2, rowbuf, pivrec, weak, ltid, barrier);
+        eliminate_block<NR, 2, 64>(m, detbuf, D, seq0 + 3, rowbuf, pivrec, weak, ltid, barrier);
+        eliminate_block<NR, 3, 64>(m, detbuf, D, seq0 + 4, rowbuf, pivrec, weak, ltid, barrier);
 #else
-        det = m[0][0];
+        if (ltid == 0) detbuf[0] = m[0][0];
 #endif
-        post_pivot_product(det, detbuf, ltid);
         barrier();
         if (ltid == 0) {
             cplx *c2 = (cplx *)A.st.c2;
