@@ -78,7 +78,7 @@ def main():
         "algorithmic_bytes_per_launch": alg,
         "traffic_over_algorithmic": (read_b + write_b + modes_b) / alg,
         "note": "step kernel + its hk_modes_kernel pre-pass (row propagators: 4*D*8 B written and read back per trajectory); "
-                "scratch traffic of the 56 B/lane the 4-waves/SIMD build spills is included in these counters",
+                "the step kernel uses no scratch memory",
     }
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)
