@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        9
+#define SC_ABI_VERSION        10
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -159,7 +159,7 @@ typedef struct sc_wm_consts {
 
 /* sGDML force field, reference semiclassical/gdml_predictor.py:57-85 (constructor) and :96-250 (forward).
  *   xs_train, jx_alphas [n_train][n_desc]: permutation-expanded training descriptors and Jacobian-contracted
- *   coefficients; pair_k/pair_l [n_desc]: atoms (k > l) of descriptor d in torch.tril_indices order;
+ *   coefficients (16-byte aligned: the kernels copy blocks of rows with 16-byte loads); pair_k/pair_l [n_desc]: atoms (k > l) of descriptor d in torch.tril_indices order;
  *   q = sqrt(5)/sigma; energies are returned relative to `origin` (potentials.py:699). */
 typedef struct sc_gdml_model {
     int32_t n_atoms, n_desc, n_train, _pad;
@@ -167,11 +167,6 @@ typedef struct sc_gdml_model {
     const int32_t *pair_k, *pair_l;
     double q, c, std, origin;
     const double *inv_mass;     /* [3 n_atoms] */
-    /* the same training data in SQUARE form, rows of row_len = sc_gdml_row_len(n_atoms) doubles (n_atoms <= 32):
-     *   xs_sq[m][a][c] = xs_train[m][pair(a, c)],  a_sq[m][a][c] = jx_alphas[m][pair(a, c)],  0 for c = a and c >= n_atoms
-     * (the J^T products of the Hessian read one contiguous row per atom and training point instead of gathering) */
-    const double *xs_sq, *a_sq;
-    int32_t row_len, _pad2;
 } sc_gdml_model;
 
 /* per-trajectory scratch of the unfused RK4 step for dense, position-dependent Hessians */
@@ -256,7 +251,8 @@ int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi
                     double mc_norm, int32_t track, int32_t has_nac, double *cq_out, double *kq_out,
                     double *partials, void *stream);
 
-/* row length of the square-form training arrays for a molecule of n_atoms atoms (8, 16, 20, 24 or 32; -1 beyond 32) */
+/* partner atoms per atom the sGDML kernel instantiated for a molecule of n_atoms atoms holds (8, 16, 20, 24 or 32);
+ * -1 beyond 32 atoms, which sc_gdml_eval / sc_gdml_stage refuse */
 int sc_gdml_row_len(int32_t n_atoms);
 
 /* E - origin [n], dE/dr [n][3N], d2E/drdr [n][3N][3N] of the sGDML model at the geometries r [n][3N].

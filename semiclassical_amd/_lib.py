@@ -60,8 +60,7 @@ class sc_gdml_model(C.Structure):
     _fields_ = [("n_atoms", C.c_int32), ("n_desc", C.c_int32), ("n_train", C.c_int32), ("_pad", C.c_int32),
                 ("xs_train", c_double_p), ("jx_alphas", c_double_p), ("pair_k", C.c_void_p), ("pair_l", C.c_void_p),
                 ("q", C.c_double), ("c", C.c_double), ("std", C.c_double), ("origin", C.c_double),
-                ("inv_mass", c_double_p), ("xs_sq", c_double_p), ("a_sq", c_double_p),
-                ("row_len", C.c_int32), ("_pad2", C.c_int32)]
+                ("inv_mass", c_double_p)]
 
 
 class sc_dense_scratch(C.Structure):
@@ -73,7 +72,7 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 9              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 10              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 

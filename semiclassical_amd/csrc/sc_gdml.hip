@@ -30,6 +30,7 @@
 // (tiles dealt round-robin to the wavefronts); the atom-pair terms are added to the accumulators element by element.
 #include "sc_common.h"
 #include "sc_prefactor.h"
+#include "sc_row16.h"
 
 namespace {
 
@@ -38,11 +39,23 @@ __device__ __forceinline__ int pair_index(int a, int b) {      // a != b; torch.
 }
 
 struct GdmlLds {
-    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *P, *Qn, *Z, *dg, *xsL, *aL, *red;
-    int XP;      // row stride of the MFMA operand arrays P = XJ, Qn = -e AJ, Z = w XJ - e AJ  ([chunk][XP])
+    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *P, *Qn, *Z, *dg, *stage, *red;
+    int XP;      // row stride of the MFMA operand arrays P = XJ, Qn = -e AJ, Z = w XJ - e AJ  ([GDML_CH][XP])
 };
 
-#define GDML_MAX_TILES 6      // 16 x 16 accumulator tiles per wavefront (21 tiles of a 30-atom molecule on 4 wavefronts)
+// Launch shapes.  A geometry with 3N <= 64 (10 Hessian tiles) takes four wavefronts, two geometries share a CU; a
+// larger one (up to 32 atoms, 21 tiles) takes eight wavefronts.  Either way a wavefront holds at most three 16 x 16
+// accumulator tiles.  A chunk has one training point per wavefront (the row reductions run one point per wavefront;
+// K = 2 GDML_CH in the GEMM).
+#define GDML_MAX_TILES 3
+__host__ __device__ inline int gdml_threads(int N) { return 3 * N <= 64 ? 256 : 512; }
+size_t gdml_lds_doubles_ch(int N, int Dd, int ch);
+// training points per chunk: one per wavefront; four for 32 atoms, whose eight-row stage buffers do not fit twice
+// (measured at 17 atoms: eight rows on four wavefronts are no faster than four)
+inline int gdml_ch(int N) {
+    if (gdml_threads(N) == 256) return 4;
+    return gdml_lds_doubles_ch(N, N * (N - 1) / 2, 8) * 8 <= 160 * 1024 ? 8 : 4;
+}
 
 // row stride of the operand arrays: 16 T (+16) doubles with stride = 16 mod 32, so that the four rows an MFMA operand
 // read touches (64 lanes x 8 bytes) fall into different LDS banks
@@ -51,9 +64,7 @@ __host__ __device__ inline int gdml_xp(int N) {
     return (T & 1) ? 16 * T : 16 * T + 16;
 }
 
-#define GDML_CHUNK_MAX 16     // training points staged per chunk (run-time choice: 16, 8 or 4, by the LDS budget)
-
-__device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt, int chunk) {
+__device__ GdmlLds gdml_carve(double *base, int N, int Dd, int GDML_CH) {
     GdmlLds L;
     double *f = base;
     L.red = f;  f += 32;
@@ -61,34 +72,68 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int Mt, int chunk) {
     L.x = f;    f += Dd;
     L.jd = f;   f += 3 * Dd;
     L.gx = f;   f += Dd;
-    L.fm = f;   f += Mt;
-    L.em = f;   f += Mt;
-    L.wm = f;   f += Mt;
-    L.ea = f;   f += Mt;
+    L.fm = f;   f += GDML_CH;
+    L.em = f;   f += GDML_CH;
+    L.wm = f;   f += GDML_CH;
+    L.ea = f;   f += GDML_CH;
     L.grad = f; f += 3 * N + (N & 1);
     L.dg = f;   f += 9 * N + (N & 1);
     L.XP = gdml_xp(N);
-    L.P = f;                           // operand arrays of the Hessian products; before that phase the same
-    L.Qn = f + chunk * L.XP;           // storage holds the per-wavefront partial sums of the descriptor gradient
-    L.Z = f + 2 * chunk * L.XP;        // (8 rows of Dd)
-    L.xsL = f;
-    L.aL = f;
+    L.P = f;    f += GDML_CH * L.XP;
+    L.Qn = f;   f += GDML_CH * L.XP;
+    L.Z = f;    f += GDML_CH * L.XP;
+    L.stage = f;                       // [2][2][GDML_CH][Dd]: two buffers of a chunk's rows of xs_train, then of jx_alphas
     return L;
 }
 
-size_t gdml_lds_doubles(int N, int Dd, int Mt, int chunk) {
-    return 32 + 3 * N + Dd + 3 * Dd + Dd + 4 * (size_t)Mt + 3 * N + (N & 1) + 9 * N + (N & 1) +
-           (3 * (size_t)chunk * gdml_xp(N) > 8 * (size_t)Dd ? 3 * (size_t)chunk * gdml_xp(N) : 8 * (size_t)Dd);
+size_t gdml_lds_doubles_ch(int N, int Dd, int GDML_CH) {
+    return 32 + 3 * N + 5 * (size_t)Dd + 4 * GDML_CH + 3 * N + (N & 1) + 9 * N + (N & 1) + 3 * (size_t)GDML_CH * gdml_xp(N) +
+           2 * 2 * (size_t)GDML_CH * Dd;
 }
+size_t gdml_lds_doubles(int N, int Dd) { return gdml_lds_doubles_ch(N, Dd, gdml_ch(N)); }
 
 // V (without origin), grad[3N] (LDS, L.grad) and hess[3N][3N] (global, row-major) at the geometry in L.pos.
-// Every thread returns the energy.
-// HN = partner atoms per half row of the square-form training data (rows of 2 HN doubles, sc_gdml_model.row_len)
-template <int HN>
-__device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess, int chunk) {
+// Every thread returns the energy.  256 threads.
+//
+// ONE pass over the training set: a chunk of GDML_CH training points (their rows of xs_train and jx_alphas are one
+// contiguous span each) is staged in LDS -- requested one chunk ahead into registers -- and serves everything that needs
+// it: the row reductions d_m, XA_m (one wavefront per training point), the descriptor-space gradient (a thread per
+// descriptor element, Neumaier-compensated over ALL training points in order), and the operands XJ_m, AJ_m of the Hessian
+// GEMM (gathered from the staged rows with the thread's Jacobian coefficients in registers).  Round 2 read the training
+// set three times per geometry (5.9 MB from L2 at 30 atoms / 200 points, the kernel's bound); this reads 1.4 MB.
+// HN = half of the partner atoms the instantiation holds (four threads share the partners of one atom), 2 HN >= N.
+template <int HN, int THREADS, int GDML_CH>
+__device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess) {
+    constexpr int nth = THREADS, nw = THREADS / 64;
     const int N = G.n_atoms, Dd = G.n_desc, Mt = G.n_train, X = 3 * N;
-    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double q = G.q;
+    // The chunk's rows (one contiguous span of GDML_CH Dd doubles per array) go from L2 straight into the stage with
+    // 16-byte LDS-DMA loads (global_load_lds_dwordx4: no registers in between, a wave instruction fills 1 KB); a partial
+    // last chunk is copied through registers and padded with zeros.  The copy of chunk k + 1 is started behind the last
+    // reader of chunk k and runs under the matrix-core phase.
+    auto stage_chunk = [&](int m0, int buf) {
+        double *stage = L.stage + buf * 2 * GDML_CH * Dd;
+        const int mc = min(GDML_CH, Mt - m0);
+        if (mc == GDML_CH) {
+            const int units = GDML_CH * Dd / 2;                      // 16-byte units per array (GDML_CH Dd is even)
+            for (int arr = 0; arr < 2; ++arr) {
+                const double *src = (arr ? G.jx_alphas : G.xs_train) + (size_t)m0 * Dd;
+                double *dst = stage + arr * GDML_CH * Dd;
+                for (int u0 = 64 * wave; u0 < units; u0 += 64 * nw) {
+                    if (u0 + lane < units)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 2 * (u0 + lane)),
+                                                         (__attribute__((address_space(3))) void *)(dst + 2 * u0), 16, 0, 0);
+                }
+            }
+        } else {
+            for (int i = tid; i < 2 * GDML_CH * Dd; i += nth) {
+                const int arr = i >= GDML_CH * Dd, ii = arr ? i - GDML_CH * Dd : i;
+                stage[i] = ii < mc * Dd ? (arr ? G.jx_alphas : G.xs_train)[(size_t)m0 * Dd + ii] : 0.0;
+            }
+        }
+    };
+    stage_chunk(0, 0);
     // ---- descriptor and Jacobian rows
     for (int d = tid; d < Dd; d += nth) {
         const int k = G.pair_k[d], l = G.pair_l[d];
@@ -98,96 +143,10 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         L.x[d] = x;
         L.jd[3 * d] = -x3 * dx; L.jd[3 * d + 1] = -x3 * dy; L.jd[3 * d + 2] = -x3 * dz;
     }
+    for (int e = tid; e < 3 * GDML_CH * L.XP; e += nth) L.P[e] = 0.0;       // P, Qn, Z are contiguous: padding columns stay 0
     __syncthreads();
-    // ---- per-training-point scalars (one wave per m, lanes over the descriptor)
-    double esum = 0.0, ssum = 0.0;
-    // four training points per wavefront and pass: their 8 row loads are in flight together and lanes 0..3 do the
-    // scalar tail (sqrt, exp) of one point each
-    for (int mq = 4 * wave; mq < Mt; mq += 4 * nw) {
-        double s2[4] = {0, 0, 0, 0}, sa[4] = {0, 0, 0, 0};
-        for (int d = lane; d < Dd; d += 64) {
-            const double xv = L.x[d];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const size_t row = (size_t)min(mq + i, Mt - 1) * Dd + d;
-                const double xd = xv - G.xs_train[row];
-                s2[i] = fma(xd, xd, s2[i]);
-                sa[i] = fma(xd, G.jx_alphas[row], sa[i]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s2[i] = wave_sum(s2[i]); sa[i] = wave_sum(sa[i]); }
-        const int m = mq + lane;
-        if (lane < 4 && m < Mt) {
-            const double s2m = lane == 0 ? s2[0] : lane == 1 ? s2[1] : lane == 2 ? s2[2] : s2[3];
-            const double sam = lane == 0 ? sa[0] : lane == 1 ? sa[1] : lane == 2 ? sa[2] : sa[3];
-            const double dist = sqrt(s2m), e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
-            const double f = e * (1.0 + q * dist) / (q * q);
-            L.fm[m] = f; L.em[m] = e; L.wm[m] = e * sam * q / dist; L.ea[m] = e * sam;
-            esum += f * sam; ssum += e * sam;
-        }
-    }
-    double red2[2] = {esum, ssum};
-    block_sum<2>(red2, L.red);
-    const double energy = red2[0] * G.std + G.c, S = red2[1];
-    __syncthreads();
-    // ---- gradient in descriptor space, then Cartesian gradient
-    // every wavefront takes a slice of the training points (lanes over the descriptor: coalesced rows), the per-wave
-    // partial sums meet in LDS (L.xsL = the storage of the Hessian operand arrays, not yet in use: one row of Dd per wavefront)
-    for (int d0 = 0; d0 < Dd; d0 += 64) {
-        const int d = d0 + lane;
-        if (d < Dd) {
-            // the terms (2e8) cancel to the size of the force (6e1): Neumaier-compensated accumulation keeps the
-            // rounding of the SUM out of the result (what remains is the rounding of the terms themselves)
-            const double xv = L.x[d];
-            double g = 0.0, comp = 0.0;
-            for (int m = wave; m < Mt; m += nw) {
-                const double t = fma(L.fm[m], G.jx_alphas[(size_t)m * Dd + d], -L.ea[m] * (xv - G.xs_train[(size_t)m * Dd + d]));
-                const double s = g + t;
-                comp += fabs(g) >= fabs(t) ? (g - s) + t : (t - s) + g;
-                g = s;
-            }
-            L.xsL[wave * Dd + d] = g + comp;
-        }
-    }
-    __syncthreads();
-    for (int d = tid; d < Dd; d += nth) {
-        double g = 0.0, comp = 0.0;
-        for (int w = 0; w < nw; ++w) {
-            const double t = L.xsL[w * Dd + d];
-            const double s = g + t;
-            comp += fabs(g) >= fabs(t) ? (g - s) + t : (t - s) + g;
-            g = s;
-        }
-        L.gx[d] = g + comp;
-    }
-    __syncthreads();
-    for (int xi = tid; xi < X; xi += nth) {
-        const int a = xi / 3, u = xi - 3 * a;
-        double g = 0.0;
-        for (int b = 0; b < N; ++b) {
-            if (b == a) continue;
-            const int d = pair_index(a, b);
-            const double j = L.jd[3 * d + u] * L.gx[d];
-            g += (a > b) ? j : -j;
-        }
-        L.grad[xi] = g * G.std;
-    }
-    // ---- Hessian.  Diagonal atom blocks of the pair terms first: dg[a] = sum_c (-S jd jd^T + d2x) over the partners
-    for (int e = tid; e < 9 * N; e += nth) {
-        const int a = e / 9, u = (e - 9 * a) / 3, v = e - 9 * a - 3 * u;
-        double acc = 0.0;
-        for (int c = 0; c < N; ++c) {
-            if (c == a) continue;
-            const int d = pair_index(a, c);
-            const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x, ix3 = -1.0 / x3;
-            const double ju = L.jd[3 * d + u], jv = L.jd[3 * d + v];
-            acc += -S * ju * jv + 3.0 * g * x5 * (ju * ix3) * (jv * ix3) - (u == v ? g * x3 : 0.0);
-        }
-        L.dg[e] = acc;
-    }
-    // rank-M sums on the matrix cores.  Tile t = c (c + 1) / 2 + r, r <= c, of the upper triangle belongs to wavefront
-    // t % nw; accumulator layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.
+    // accumulator tiles of the rank-M sums on the matrix cores.  Tile t = c (c + 1) / 2 + r, r <= c, of the upper triangle
+    // belongs to wavefront t % nw; accumulator layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.
     typedef double d4 __attribute__((ext_vector_type(4)));
     const int XP = L.XP, T = (X + 15) / 16, ntiles = T * (T + 1) / 2, rg = lane >> 4, li = lane & 15;
     d4 acc[GDML_MAX_TILES];
@@ -200,15 +159,23 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         while ((c + 1) * (c + 2) / 2 <= t) ++c;
         tr_[sl] = t - c * (c + 1) / 2; tc_[sl] = c;
     }
-    for (int e = tid; e < 3 * chunk * XP; e += nth) L.P[e] = 0.0;       // P, Qn, Z are contiguous: padding columns stay 0
-    // formation roles: thread = (training point slot, atom, half of the partner atoms)
-    const int fm_rows = nth / (2 * N) < chunk ? nth / (2 * N) : chunk;      // training points formed per pass
-    const int fm_half = tid & 1, fm_at = (tid >> 1) % N, fm_mm = (tid >> 1) / N;
-    const bool fm_active = fm_mm < fm_rows;
-    double coef[3][HN], base[3] = {0.0, 0.0, 0.0};
+    // formation roles: thread = (MPT of the chunk's training points, atom, quarter of the partner atoms); its
+    // Jacobian coefficients coef[u][c] = +-jd[pair(a, c)][u] stay in registers (3 QN doubles):
+    //   XJ_m[a, u] = base[u] - sum_c coef[u][c] xs_m[pair(a, c)],   AJ_m[a, u] = sum_c coef[u][c] A_m[pair(a, c)]
+    // the four partial sums of a row sit in adjacent lanes and meet by two quad-permute additions
+    constexpr int PARTS = 4, QN = (2 * HN + PARTS - 1) / PARTS;
+    constexpr int MPT = GDML_CH * 4 * 32 > THREADS * 2 ? 4 : 2;     // training points per thread: 4 N (GDML_CH / MPT) <= THREADS
+    const int fm_q = tid % PARTS, fm_at = (tid / PARTS) % N, fm_mh = (tid / PARTS) / N;
+    const bool fm_active = fm_mh < GDML_CH / MPT;
+    auto parts_sum = [](double v) {
+        v += dpp_mov_f64<0xB1>(v);                       // quad_perm [1,0,3,2]
+        v += dpp_mov_f64<0x4E>(v);                       // quad_perm [2,3,0,1]
+        return v;
+    };
+    double coef[3][QN], base[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int cc = 0; cc < HN; ++cc) {
-        const int c = HN * fm_half + cc;
+    for (int cc = 0; cc < QN; ++cc) {
+        const int c = QN * fm_q + cc;
         const bool ok = c < N && c != fm_at;
         const int d = ok ? pair_index(fm_at, c) : 0;
         const double xq = ok ? L.x[d] : 0.0;
@@ -220,73 +187,178 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         }
     }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) base[u] += dpp_mov_f64<0xB1>(base[u]);    // both halves of the partner sum
-    for (int m0 = 0; m0 < Mt; m0 += chunk) {
-        const int mc = min(chunk, Mt - m0);
-        __syncthreads();
-        // XJ_m = J^T xd_m, AJ_m = J^T A_m for the chunk, from the SQUARE form of the training data
-        //   xs_sq[m][a][c] = xs_m[pair(a, c)],  a_sq[m][a][c] = A_m[pair(a, c)]   (rows of 32 doubles, zero for c = a, c >= N)
-        // read straight from L2 (the rows of one atom are contiguous): a thread pair (half = 0, 1) owns (atom a, training
-        // point mm), each half takes 16 partner atoms with its coefficients coef[u][c] = +-jd[pair(a, c)][u] in
-        // registers (loaded once per geometry), so a training value feeds three multiply-adds and nothing is gathered:
-        //   XJ_m[a, u] = base[u] - sum_c coef[u][c] xs_sq[m][a][c],   AJ_m[a, u] = sum_c coef[u][c] a_sq[m][a][c]
-        if (mc < chunk)                                  // last, partial chunk: its unused operand rows must be zero
-            for (int e = mc * XP + tid; e < chunk * XP; e += nth) { L.P[e] = 0.0; L.Qn[e] = 0.0; L.Z[e] = 0.0; }
-#ifndef GDML_ABLATE_FORM
-        for (int pass = 0; pass < chunk; pass += fm_rows) {
-            const int mm = pass + fm_mm;
-            double sx[3] = {0.0, 0.0, 0.0}, sa[3] = {0.0, 0.0, 0.0};
-            if (fm_active && mm < mc) {
-                const size_t row = (((size_t)(m0 + mm) * N + fm_at) * (2 * HN) + HN * fm_half);
-                const double2 *xr = (const double2 *)(G.xs_sq + row), *ar = (const double2 *)(G.a_sq + row);
-                double2 xv[HN / 2], av[HN / 2];
+    for (int u = 0; u < 3; ++u) base[u] = parts_sum(base[u]);     // complete in the lane of part 0
+    // descriptor-space gradient g_x[d] = sum_m f_m A_m[d] - e_m XA_m (x[d] - xs_m[d]) of this thread's elements d = tid,
+    // tid + 256.  The terms (2e8) cancel to the size of the force (6e1): Neumaier-compensated accumulation keeps the
+    // rounding of the SUM out of the result (what remains is the rounding of the terms themselves)
+    constexpr int EPT = (512 + nth - 1) / nth;           // descriptor elements per thread (Dd <= 496)
+    double gacc[EPT], gcomp[EPT], xown[EPT];
 #pragma unroll
-                for (int i = 0; i < HN / 2; ++i) { xv[i] = xr[i]; av[i] = ar[i]; }
-#pragma unroll
-                for (int i = 0; i < HN / 2; ++i) {
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        sx[u] = fma(coef[u][2 * i], xv[i].x, sx[u]); sx[u] = fma(coef[u][2 * i + 1], xv[i].y, sx[u]);
-                        sa[u] = fma(coef[u][2 * i], av[i].x, sa[u]); sa[u] = fma(coef[u][2 * i + 1], av[i].y, sa[u]);
-                    }
-                }
+    for (int j = 0; j < EPT; ++j) { gacc[j] = 0.0; gcomp[j] = 0.0; xown[j] = tid + nth * j < Dd ? L.x[tid + nth * j] : 0.0; }
+    double esum = 0.0, ssum = 0.0;
+    double sx[MPT][3], sa3[MPT][3];
+    // (1) row reductions of the training points this wavefront owns in the chunk at m0: d_m^2 = |x - xs_m|^2,
+    //     XA_m = (x - xs_m) . A_m (lanes over the descriptor), then the scalars e_m, f_m, w_m (gdml_predictor.py:150-170)
+    auto row_scalars = [&](int m0, const double *sxs, const double *sal) {
+        for (int mm = wave; mm < min(GDML_CH, Mt - m0); mm += nw) {
+            double s2 = 0.0, sa = 0.0;
+#ifdef GDML_ABLATE_ROWRED
+            for (int d = lane; d < 64; d += 64) {
+#else
+            for (int d = lane; d < Dd; d += 64) {
+#endif
+                const double xd = L.x[d] - sxs[mm * Dd + d];
+                s2 = fma(xd, xd, s2);
+                sa = fma(xd, sal[mm * Dd + d], sa);
             }
-            // the two halves of a row sit in adjacent lanes
+            s2 = wave_sum(s2); sa = wave_sum(sa);
+            if (lane == 0) {
+#ifdef GDML_ABLATE_TAIL
+                const double dist = 1.0 + s2, e = 1.0 - q * dist;
+#else
+                const double dist = sqrt(s2), e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
+#endif
+                const double f = e * (1.0 + q * dist) / (q * q);
+                L.fm[mm] = f; L.em[mm] = e; L.wm[mm] = e * sa * q / dist; L.ea[mm] = e * sa;
+                esum += f * sa; ssum += e * sa;
+            }
+        }
+    };
+    // (2) J^T xs_m, J^T A_m of this thread's atom for its two training points (rows beyond a partial chunk are zero)
+    const int fm_row = fm_active ? MPT * fm_mh : 0, tri = fm_at * (fm_at - 1) / 2;   // threads without a role never gather
+    int pidx[QN];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) { sx[u] += dpp_mov_f64<0xB1>(sx[u]); sa[u] += dpp_mov_f64<0xB1>(sa[u]); }   // quad_perm [1,0,3,2]
-            if (fm_active && fm_half == 0 && mm < mc) {
-                const double w = L.wm[m0 + mm], em = L.em[m0 + mm];
+    for (int cc = 0; cc < QN; ++cc) {
+        // position of pair (a, c) in a descriptor row; partners outside the molecule (and c = a) have coef = 0
+        const int c = min(QN * fm_q + cc, N - 1);
+        pidx[cc] = c < fm_at ? tri + c : (c > fm_at ? c * (c - 1) / 2 + fm_at : 0);
+    }
+    auto gather_begin = [&]() {
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const double xj = base[u] - sx[u], q = -em * sa[u];
-                    L.P[mm * XP + 3 * fm_at + u] = xj; L.Qn[mm * XP + 3 * fm_at + u] = q; L.Z[mm * XP + 3 * fm_at + u] = fma(w, xj, q);
+        for (int i = 0; i < MPT; ++i)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { sx[i][u] = 0.0; sa3[i][u] = 0.0; }
+    };
+    auto gather_partner = [&](auto ccc, const double *sxs, const double *sal) {
+        constexpr int cc = decltype(ccc)::value;
+#ifndef GDML_ABLATE_FORM
+        const double *xr = sxs + fm_row * Dd, *ar = sal + fm_row * Dd;
+#pragma unroll
+        for (int i = 0; i < MPT; ++i) {
+            const double xv = xr[i * Dd + pidx[cc]], av = ar[i * Dd + pidx[cc]];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { sx[i][u] = fma(coef[u][cc], xv, sx[i][u]); sa3[i][u] = fma(coef[u][cc], av, sa3[i][u]); }
+        }
+#endif
+    };
+    auto gather_end = [&]() {
+#pragma unroll
+        for (int i = 0; i < MPT; ++i)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) { sx[i][u] = parts_sum(sx[i][u]); sa3[i][u] = parts_sum(sa3[i][u]); }
+    };
+    // Chunk loop, two stage buffers, two barriers per chunk:
+    //     (1) row scalars, (2) gathers of chunk k | B1 | (3) gradient terms, (4) operand rows | B2 | (5) MFMAs
+    // The copy of chunk k + 1 into the other buffer starts at the top of chunk k (the readers of that buffer finished
+    // before B2 of chunk k - 1) and must have landed at B2 of chunk k.  (5) of chunk k is followed by (1), (2) of chunk
+    // k + 1 without a barrier: different data.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wavefront's part of the first chunk has landed
+    __syncthreads();
+    for (int m0 = 0, buf = 0; m0 < Mt; m0 += GDML_CH, buf ^= 1) {
+        const int mc = min(GDML_CH, Mt - m0);
+        const double *sxs = L.stage + buf * 2 * GDML_CH * Dd, *sal = sxs + GDML_CH * Dd;
+        if (m0 + GDML_CH < Mt) stage_chunk(m0 + GDML_CH, buf ^ 1);
+        row_scalars(m0, sxs, sal);
+        gather_begin();
+        if (fm_active) sfor<0, QN>([&](auto ccc) { gather_partner(ccc, sxs, sal); });
+        gather_end();
+        __syncthreads();
+        // (3) gradient terms of the chunk, (4) operand rows of the chunk
+#ifndef GDML_ABLATE_GRAD
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int d = tid + nth * j;
+            if (d < Dd) {
+                for (int mm = 0; mm < mc; ++mm) {
+                    const double t = fma(L.fm[mm], sal[mm * Dd + d], -L.ea[mm] * (xown[j] - sxs[mm * Dd + d]));
+                    const double sn = gacc[j] + t;
+                    gcomp[j] += fabs(gacc[j]) >= fabs(t) ? (gacc[j] - sn) + t : (t - sn) + gacc[j];
+                    gacc[j] = sn;
                 }
             }
         }
 #endif
+        if (fm_active && fm_q == 0) {
+#pragma unroll
+            for (int i = 0; i < MPT; ++i) {
+                const int mm = MPT * fm_mh + i;
+                const bool in = mm < mc;                 // rows of a partial last chunk are zero
+                const double w = in ? L.wm[mm] : 0.0, em = in ? L.em[mm] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const double xj = in ? base[u] - sx[i][u] : 0.0, qv = -em * sa3[i][u];
+                    L.P[mm * XP + 3 * fm_at + u] = xj; L.Qn[mm * XP + 3 * fm_at + u] = qv; L.Z[mm * XP + 3 * fm_at + u] = fma(w, xj, qv);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // this wavefront's part of chunk k + 1 has landed
         __syncthreads();
+        // (5) [XJ ; -e AJ]^T [Z ; XJ] of the chunk on the matrix cores
 #ifndef GDML_ABLATE_MFMA
 #pragma unroll
         for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
             if (wave + sl * nw >= ntiles) continue;               // wave-uniform
             const double *ar = L.P + rg * XP + 16 * tr_[sl] + li, *bc = L.Z + rg * XP + 16 * tc_[sl] + li;
             const double *aq = L.Qn + rg * XP + 16 * tr_[sl] + li, *bp = L.P + rg * XP + 16 * tc_[sl] + li;
-            for (int ks = 0; ks < chunk / 4; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < GDML_CH / 4; ++ks) {
                 acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks * XP], bc[4 * ks * XP], acc[sl], 0, 0, 0);
                 acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[4 * ks * XP], bp[4 * ks * XP], acc[sl], 0, 0, 0);
             }
         }
 #endif
     }
-    __syncthreads();         // dg complete (written before the chunk loop's first barrier anyway)
+    double red2[2] = {esum, ssum};
+    block_sum<2>(red2, L.red);
+    const double energy = red2[0] * G.std + G.c, S = red2[1];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if (tid + nth * j < Dd) L.gx[tid + nth * j] = gacc[j] + gcomp[j];
+    __syncthreads();
+    // ---- Cartesian gradient
+    for (int xi = tid; xi < X; xi += nth) {
+        const int a = xi / 3, u = xi - 3 * a;
+        double g = 0.0;
+        for (int b = 0; b < N; ++b) {
+            if (b == a) continue;
+            const int d = pair_index(a, b);
+            const double j = L.jd[3 * d + u] * L.gx[d];
+            g += (a > b) ? j : -j;
+        }
+        L.grad[xi] = g * G.std;
+    }
+    // ---- Hessian.  Diagonal atom blocks of the pair terms: dg[a] = sum_c (-S jd jd^T + d2x) over the partners
+    for (int e = tid; e < 9 * N; e += nth) {
+        const int a = e / 9, u = (e - 9 * a) / 3, v = e - 9 * a - 3 * u;
+        double sum = 0.0;
+        for (int c = 0; c < N; ++c) {
+            if (c == a) continue;
+            const int d = pair_index(a, c);
+            const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x, ix3 = -1.0 / x3;
+            const double ju = L.jd[3 * d + u], jv = L.jd[3 * d + v];
+            sum += -S * ju * jv + 3.0 * g * x5 * (ju * ix3) * (jv * ix3) - (u == v ? g * x3 : 0.0);
+        }
+        L.dg[e] = sum;
+    }
+    __syncthreads();
     // atom-pair terms element by element, scale, write both triangles
 #pragma unroll
     for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
         if (wave + sl * nw >= ntiles) continue;
         const int y = 16 * tc_[sl] + li, b = y / 3, v = y - 3 * b;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int xr = 16 * tr_[sl] + rg + 4 * q, a = xr / 3, u = xr - 3 * a;
+        for (int qq = 0; qq < 4; ++qq) {
+            const int xr = 16 * tr_[sl] + rg + 4 * qq, a = xr / 3, u = xr - 3 * a;
             if (xr >= X || y >= X || (tr_[sl] == tc_[sl] && xr > y)) continue;
             double fin;
             if (a == b) fin = L.dg[9 * a + 3 * u + v];
@@ -296,7 +368,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                 const double ju = L.jd[3 * d + u], jv = L.jd[3 * d + v];
                 fin = S * ju * jv - (3.0 * g * x5 * (ju * ix3) * (jv * ix3) - (u == v ? g * x3 : 0.0));
             }
-            const double val = (acc[sl][q] + fin) * G.std;
+            const double val = (acc[sl][qq] + fin) * G.std;
             hess[(size_t)xr * X + y] = val;
             hess[(size_t)y * X + xr] = val;
         }
@@ -308,22 +380,21 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
 // ------------------------------------------------------------------ function-level evaluation
 struct EvalArgs {
     sc_gdml_model G;
-    int chunk;
     const double *r;
     int64_t n;
     double *energy, *grad, *hess;
 };
 
-template <int THREADS, int HN>
-__global__ __launch_bounds__(THREADS, 512 / THREADS) void gdml_eval_kernel(EvalArgs A) {
+template <int THREADS, int HN, int CH>
+__global__ __launch_bounds__(THREADS, 2) void gdml_eval_kernel(EvalArgs A) {
     extern __shared__ double smem[];
     const int X = 3 * A.G.n_atoms;
-    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train, A.chunk);
+    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, CH);
     for (int64_t tr = blockIdx.x; tr < A.n; tr += gridDim.x) {
         __syncthreads();
         for (int i = threadIdx.x; i < X; i += blockDim.x) L.pos[i] = A.r[tr * X + i];
         __syncthreads();
-        const double e = gdml_eval_device<HN>(A.G, L, A.hess + (size_t)tr * X * X, A.chunk);
+        const double e = gdml_eval_device<HN, THREADS, CH>(A.G, L, A.hess + (size_t)tr * X * X);
         for (int i = threadIdx.x; i < X; i += blockDim.x) A.grad[tr * X + i] = L.grad[i];
         if (threadIdx.x == 0) A.energy[tr] = e - A.G.origin;
     }
@@ -332,7 +403,6 @@ __global__ __launch_bounds__(THREADS, 512 / THREADS) void gdml_eval_kernel(EvalA
 // ------------------------------------------------------------------ RK4 stage of (q, p, S)
 struct StageArgs {
     sc_gdml_model G;
-    int chunk;
     sc_state st;
     sc_dense_scratch sc;
     double dt;
@@ -340,11 +410,11 @@ struct StageArgs {
     double *epart;
 };
 
-template <int THREADS, int HN>
-__global__ __launch_bounds__(THREADS, 512 / THREADS) void gdml_stage_kernel(StageArgs A) {
+template <int THREADS, int HN, int CH>
+__global__ __launch_bounds__(THREADS, 2) void gdml_stage_kernel(StageArgs A) {
     extern __shared__ double smem[];
     const int D = A.st.dim, tid = threadIdx.x, nth = blockDim.x, s = A.stage;
-    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, A.G.n_train, A.chunk);
+    const GdmlLds L = gdml_carve(smem, A.G.n_atoms, A.G.n_desc, CH);
     const double dt = A.dt, c = (s == 0) ? 0.0 : (s == 3 ? dt : 0.5 * dt), w = (s == 0 || s == 3) ? 1.0 : 2.0;
     const double h6 = dt / 6.0;
     double esum = 0.0;
@@ -359,7 +429,7 @@ __global__ __launch_bounds__(THREADS, 512 / THREADS) void gdml_stage_kernel(Stag
             ps[j] = qp[D + i] + c * kp;
         }
         __syncthreads();
-        const double e = gdml_eval_device<HN>(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D, A.chunk) - A.G.origin;
+        const double e = gdml_eval_device<HN, THREADS, CH>(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D) - A.G.origin;
         double tk[1] = {0.0};
         for (int i = tid, j = 0; i < D; i += nth, ++j) {
             const double im = A.G.inv_mass[i], kq = ps[j] * im, kp = -L.grad[i];
@@ -379,8 +449,6 @@ __global__ __launch_bounds__(THREADS, 512 / THREADS) void gdml_stage_kernel(Stag
     if (tid == 0 && A.epart && s == 3) A.epart[blockIdx.x] = esum;
 }
 
-// training points per staged chunk: the largest of 16, 8, 4 that fits LDS (measured at 30 atoms: a smaller chunk that
-// lets two workgroups share a CU is slower -- more chunk iterations, each with three barriers); the per-wave partial
 }  // namespace
 
 extern "C" int sc_gdml_row_len(int32_t n_atoms) {
@@ -391,28 +459,19 @@ extern "C" int sc_gdml_row_len(int32_t n_atoms) {
 
 namespace {
 
-int gdml_chunk(const sc_gdml_model *g, int threads) {
-    (void)threads;
-    const int minc = 4;
-    for (int c = GDML_CHUNK_MAX; c >= minc; c /= 2)
-        if (gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, c) * 8 <= 160 * 1024) return c;
-    return 0;
-}
-
 int check_model(const sc_gdml_model *g, const char *who) {
     if (!g || !g->xs_train || !g->jx_alphas || !g->pair_k || !g->pair_l)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null model field", who);
-    if (!g->xs_sq || !g->a_sq) return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null square-form training arrays", who);
-    if (g->n_atoms > 32) return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms (the square-form rows hold 32)", who, g->n_atoms);
-    if (g->row_len != sc_gdml_row_len(g->n_atoms))
-        return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: row_len %d, %d atoms need %d", who, g->row_len, g->n_atoms, sc_gdml_row_len(g->n_atoms));
+    if (g->n_atoms > 32) return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms (four threads hold the coefficients of 32 partner atoms)", who, g->n_atoms);
+    if (((uintptr_t)g->xs_train | (uintptr_t)g->jx_alphas) & 15)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: xs_train / jx_alphas must be 16-byte aligned", who);
     if (g->n_desc != g->n_atoms * (g->n_atoms - 1) / 2)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: descriptor size %d does not match %d atoms", who, g->n_desc, g->n_atoms);
-    if (gdml_chunk(g, 256) == 0)
-        return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d, M=%d) needs more than 160 KiB of LDS", who, g->n_atoms, g->n_train);
+    if (gdml_lds_doubles(g->n_atoms, g->n_desc) * 8 > 160 * 1024)
+        return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d) needs more than 160 KiB of LDS", who, g->n_atoms);
     {
-        const int T = (3 * g->n_atoms + 15) / 16, nw = 4;
-        if (T * (T + 1) / 2 > GDML_MAX_TILES * nw)
+        const int T = (3 * g->n_atoms + 15) / 16;
+        if (T * (T + 1) / 2 > GDML_MAX_TILES * (gdml_threads(g->n_atoms) / 64))
             return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms need more Hessian tiles than the kernel holds", who, g->n_atoms);
     }
     return SC_OK;
@@ -426,19 +485,23 @@ extern "C" int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, 
     if (rc) return rc;
     if (!r || !energy || !grad || !hess) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_eval: null argument");
     if (n <= 0) return SC_OK;
-    const int chunk = gdml_chunk(g, 256);          // four wavefronts per geometry: two geometries share a CU
-    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, chunk) * 8;
-    EvalArgs a{*g, chunk, r, n, energy, grad, hess};
+    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc) * 8;
+    EvalArgs a{*g, r, n, energy, grad, hess};
     const int grid = (int)(n < 1024 ? n : 1024);
-#define SC_GDML_EVAL(HN_)                                                                                                  \
-    case 2 * HN_:                                                                                                          \
-        if (hipFuncSetAttribute((const void *)gdml_eval_kernel<256, HN_>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+#define SC_GDML_EVAL(TH_, HN_, CH_)                                                                                        \
+    if (threads == TH_ && row_len == 2 * HN_ && ch == CH_) {                                                               \
+        if (hipFuncSetAttribute((const void *)gdml_eval_kernel<TH_, HN_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds) != hipSuccess)                                                                   \
             return sc_check_launch("sc_gdml_eval (LDS attribute)");                                                        \
-        hipLaunchKernelGGL((gdml_eval_kernel<256, HN_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a);              \
-        break;
-    switch (g->row_len) { SC_GDML_EVAL(4) SC_GDML_EVAL(8) SC_GDML_EVAL(10) SC_GDML_EVAL(12) SC_GDML_EVAL(16) }
+        hipLaunchKernelGGL((gdml_eval_kernel<TH_, HN_, CH_>), dim3(grid), dim3(TH_), lds, (hipStream_t)stream, a);         \
+        launched = true;                                                                                                   \
+    }
+    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms);
+    bool launched = false;
+    SC_GDML_EVAL(256, 4, 4) SC_GDML_EVAL(256, 8, 4) SC_GDML_EVAL(256, 10, 4) SC_GDML_EVAL(256, 12, 4)
+    SC_GDML_EVAL(512, 12, 8) SC_GDML_EVAL(512, 16, 8) SC_GDML_EVAL(512, 16, 4)
 #undef SC_GDML_EVAL
+    if (!launched) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_eval: no kernel for %d atoms", g->n_atoms);
     return sc_check_launch("sc_gdml_eval");
 }
 
@@ -454,17 +517,21 @@ extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const s
     if (stage < 0 || stage > 3) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_gdml_stage: stage %d", stage);
     if (st->dim > 512) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_stage: D=%d > 512", st->dim);
     if (st->n <= 0) return SC_OK;
-    const int chunk = gdml_chunk(g, 256);
-    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc, g->n_train, chunk) * 8;
-    StageArgs a{*g, chunk, *st, *sc, dt, stage, energy_partials};
-#define SC_GDML_STAGE(HN_)                                                                                                 \
-    case 2 * HN_:                                                                                                          \
-        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<256, HN_>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+    const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc) * 8;
+    StageArgs a{*g, *st, *sc, dt, stage, energy_partials};
+#define SC_GDML_STAGE(TH_, HN_, CH_)                                                                                       \
+    if (threads == TH_ && row_len == 2 * HN_ && ch == CH_) {                                                               \
+        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<TH_, HN_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds) != hipSuccess)                                                                   \
             return sc_check_launch("sc_gdml_stage (LDS attribute)");                                                       \
-        hipLaunchKernelGGL((gdml_stage_kernel<256, HN_>), dim3(sc_dense_grid(st->n)), dim3(256), lds, (hipStream_t)stream, a); \
-        break;
-    switch (g->row_len) { SC_GDML_STAGE(4) SC_GDML_STAGE(8) SC_GDML_STAGE(10) SC_GDML_STAGE(12) SC_GDML_STAGE(16) }
+        hipLaunchKernelGGL((gdml_stage_kernel<TH_, HN_, CH_>), dim3(sc_dense_grid(st->n)), dim3(TH_), lds, (hipStream_t)stream, a); \
+        launched = true;                                                                                                   \
+    }
+    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms);
+    bool launched = false;
+    SC_GDML_STAGE(256, 4, 4) SC_GDML_STAGE(256, 8, 4) SC_GDML_STAGE(256, 10, 4) SC_GDML_STAGE(256, 12, 4)
+    SC_GDML_STAGE(512, 12, 8) SC_GDML_STAGE(512, 16, 8) SC_GDML_STAGE(512, 16, 4)
 #undef SC_GDML_STAGE
+    if (!launched) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_stage: no kernel for %d atoms", g->n_atoms);
     return sc_check_launch("sc_gdml_stage");
 }

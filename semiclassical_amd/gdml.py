@@ -33,6 +33,7 @@ class MolecularGDMLPotential(_MolecularPotentialBase):
         self._jx_alphas = expand(torch.tensor(np.asarray(model['R_d_desc_alpha'], dtype=np.float64)))
         self._sig, self._c, self._std = int(model['sig']), float(model['c']), float(model.get('std', 1))
         self._n_atoms = int(n_atoms)
+        assert lib.sc_gdml_row_len(self._n_atoms) > 0, "the sGDML kernels hold molecules of up to 32 atoms"
         k, l = torch.tril_indices(n_atoms, n_atoms, offset=-1)
         self._pair_k, self._pair_l = k.to(torch.int32).contiguous(), l.to(torch.int32).contiguous()
         self._default_device = device
@@ -46,27 +47,13 @@ class MolecularGDMLPotential(_MolecularPotentialBase):
         key = str(device)
         if key not in self._model_cache:
             up = lambda t: t.to(device)
-            bufs = [up(self._xs_train), up(self._jx_alphas), up(self._pair_k), up(self._pair_l), up(1.0 / self._masses),
-                    up(self._square(self._xs_train)), up(self._square(self._jx_alphas))]
+            bufs = [up(self._xs_train), up(self._jx_alphas), up(self._pair_k), up(self._pair_l), up(1.0 / self._masses)]
             m = sc_gdml_model(n_atoms=self._n_atoms, n_desc=self._xs_train.shape[1], n_train=self._xs_train.shape[0],
                               xs_train=ptr(bufs[0]), jx_alphas=ptr(bufs[1]), pair_k=ptr(bufs[2]), pair_l=ptr(bufs[3]),
                               q=float(np.sqrt(5) / self._sig), c=self._c, std=self._std, origin=float(self._origin),
-                              inv_mass=ptr(bufs[4]), xs_sq=ptr(bufs[5]), a_sq=ptr(bufs[6]),
-                              row_len=lib.sc_gdml_row_len(self._n_atoms))
+                              inv_mass=ptr(bufs[4]))
             self._model_cache[key] = (m, bufs)
         return self._model_cache[key][0]
-
-    def _square(self, rows):
-        """(M, Dd) descriptor-space rows -> (M, N, row_len): value of pair (a, c) at [m, a, c] and [m, c, a], zeros
-        elsewhere (the layout sc_gdml_model.xs_sq / a_sq documents)"""
-        n = self._n_atoms
-        row_len = lib.sc_gdml_row_len(n)
-        assert row_len > 0, "the sGDML kernels hold molecules of up to 32 atoms"
-        out = torch.zeros((rows.shape[0], n, row_len), dtype=torch.float64)
-        k, l = self._pair_k.long(), self._pair_l.long()
-        out[:, k, l] = rows
-        out[:, l, k] = rows
-        return out.contiguous()
 
     def harmonic_approximation(self, r):
         """V (n,), grad (D, n), hess (D, D, n) for positions r (D, n) -- evaluated on the GPU"""

@@ -130,3 +130,34 @@ def test_gdml_30_atoms_matches_oracle():
     dy, dc2 = cases.rel_err(cnp(prop.y), oprop.y.numpy()), cases.rel_err(cnp(prop._c2), oprop.c2.numpy())
     print(f"two HK steps at D = 90: y {dy:.2e}  c2 {dc2:.2e}")
     assert dy < TOL30[3] and dc2 < TOL30[4]
+
+
+@pytest.mark.parametrize("N,M", [(5, 37), (12, 50), (19, 61), (21, 44), (24, 83), (28, 70), (32, 45), (32, 3)])
+def test_gdml_launch_shapes_and_partial_chunks(N, M):
+    """every instantiation of the sGDML kernels (4 or 8 wavefronts per geometry, 4 or 8 training points per chunk, the
+    partner-coefficient counts of 8 ... 32 atoms) with a training-set size that leaves a partial last chunk: E, grad,
+    Hessian against the CPU oracle on a synthetic model"""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd.gdml import MolecularGDMLPotential
+    torch.set_default_dtype(torch.float64)
+    model, pos = synthetic_model(N, M, 100 + N)
+    g0 = orc.GDMLOracle(model).forward(torch.from_numpy(pos.reshape(1, -1)))[1]
+    model["R_d_desc_alpha"] = model["R_d_desc_alpha"] * (0.02 / float(g0.abs().max()))
+
+    class _Fchk(object):
+        def nonadiabatic_coupling(self_):
+            return np.zeros(3 * N)
+
+        def masses(self_):
+            return np.repeat(np.full(N, 12.0 * 1822.888), 3)
+
+        def atomic_numbers(self_):
+            return model["z"]
+    pot = MolecularGDMLPotential(model, _Fchk())
+    r = torch.from_numpy(pos.reshape(1, -1) + np.random.default_rng(N).normal(0, 0.05, (5, 3 * N)))
+    e_ref, g_ref, h_ref = orc.GDMLOracle(model).forward(r)
+    v, grad, hess = pot.harmonic_approximation(r.t().contiguous().cuda())
+    dev = (cases.rel_err(cnp(v), e_ref.numpy()), cases.rel_err(cnp(grad.t()), g_ref.numpy()),
+           cases.rel_err(cnp(hess.permute(2, 0, 1)), h_ref.numpy()))
+    print(f"N={N} M={M}: E {dev[0]:.2e}  grad {dev[1]:.2e}  hess {dev[2]:.2e}")
+    assert dev[0] < 1e-11 and dev[1] < 1e-11 and dev[2] < 1e-11
