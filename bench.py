@@ -201,7 +201,7 @@ def config3(dev, n, steps):
     wm_ms, hk_ms = k["wm"], k["hk_step"]
     return {"workload": f"harmonic methylium D=12 d'=6, WM alpha=beta=1e4, n={n} (BASELINE.json configs[2])", "n": n, "steps": steps,
             "ms_per_step": wall / steps * 1e3, "value": n * steps / wall, "unit": "trajectory-steps/s",
-            "kernels_ms": {"wm_small_kernel<12,6>": wm_ms, "hk_step_kernel<true> (RK4 + HK prefactor)": hk_ms},
+            "kernels_ms": {"wm_small_kernel<12,6>": wm_ms, "hk_step_lin_kernel<12,6,false> (RK4 + HK prefactor)": hk_ms},
             "roofline": {"kernel": "wm_small_kernel<12,6>", "bound": "fp64", "achieved": flops / (wm_ms * 1e-3) / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (wm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": flops,
