@@ -266,7 +266,7 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     int dbg = 0;
 #ifdef SC_TUNING   // experiment knobs exist only in the tuning build (tools/mkvar.sh); the product library reads no environment
     if (getenv("SC_FORCE_GENERAL_STEP")) fast = false;
-    dbg = (getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0) | (getenv("SC_DEBUG_FORCE_FIXUP") ? 0x400 : 0);
+    dbg = getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0;      // the fix-up launch is skipped (the ablated kernel is a variant library, SC_SD_ABLATE_LU)
 #endif
     if (fast) {
         StepArgs a{*pot, *st, *hk, dt, mode | dbg, energy_partials};

@@ -41,6 +41,12 @@
 #ifndef SC_SD_XPREFETCH
 #define SC_SD_XPREFETCH 1  // request row slot 0 of the next trajectory before the last diagonal block of the elimination
 #endif
+#ifndef SC_SD_ABLATE_LU
+#define SC_SD_ABLATE_LU 0  // 1: variant library without the elimination (streaming phase alone)
+#endif
+#ifndef SC_SD_FORCE_FIXUP
+#define SC_SD_FORCE_FIXUP 0
+#endif
 #ifndef SC_SD_BLOCK_BARRIER
 #define SC_SD_BLOCK_BARRIER no_barrier     // wg_barrier: a workgroup barrier in front of every diagonal block
 #endif
@@ -108,11 +114,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         const int tl = (wave_s << 6) | (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
         const int tj = tl & 15, tjl = tj;
         const int til = (tl >> 6) * 4 + ((tl >> 4) & 3);    // wave w holds rows 4w .. 4w+3 of every 16-row slot
-#ifdef SC_TUNING
-        if (tl == 0) *weak = (A.mode & 0x400) ? 1 : 0;     // 0x400: tuning build, force the fallback (SC_DEBUG_FORCE_FIXUP)
-#else
-        if (tl == 0) *weak = 0;
-#endif
+        if (tl == 0) *weak = SC_SD_FORCE_FIXUP;             // 1: variant library that hands every trajectory to the fallback
         if (tl < 16) detbuf[par][tl] = c_make(1.0, 0.0);
         int drawn = 0;
         if (cursor && tl == 0) drawn = atomicAdd(cursor, 1);
@@ -220,11 +222,9 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         });
 
         // ---------------- phase C: determinant in registers ----------------
-#ifdef SC_TUNING
-        const bool skip_lu = (A.mode & 0x100) != 0;      // tuning build only: phase ablation (SC_DEBUG_SKIP_LU)
-#else
-        constexpr bool skip_lu = false;
-#endif
+        // phase ablation (tools/phase_timing.py) is a COMPILE-time switch of a variant library: a run-time flag here costs the
+        // kernel 148 B/lane of scratch and 30 % of its speed
+        constexpr bool skip_lu = SC_SD_ABLATE_LU != 0;
         if (cursor && tl == 0) nextbuf[par] = drawn;
         // Only block 0 starts behind a barrier (it also orders the resets above).  Later blocks need none: a wave
         // owns every fourth pivot step, so when step s is published every wave has consumed step s - 4, and a row
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         (void)no_barrier;
         sfor<0, NR>([&](auto kbc) {
             constexpr int KB = decltype(kbc)::value;
+            if (KB == 0 && skip_lu) __syncthreads();   // elimination ablated: the barrier block 0 would have had
             if (KB == (NR > 1 ? 1 : 0)) {            // behind the barrier of block 0 (NR = 1: the value is read after the last barrier)
                 if (NR > 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
             }

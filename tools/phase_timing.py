@@ -2,8 +2,10 @@
 """Ablation timing of the step kernel on the bench workload (debug tool, GPU box only).
 
 Usage: python tools/phase_timing.py [ntraj]
-Times (HIP events on the launch stream): the full step, the step without the elimination
-(SC_DEBUG_SKIP_LU=1) and the prefactor-only launch (loads + matrix + elimination, no RK4 / stores).
+Times (HIP events on the launch stream): the full step and the prefactor-only launch (loads + matrix + elimination, no
+RK4 / stores).  The elimination is ablated at COMPILE time (a run-time switch costs the kernel its register allocation):
+    tools/mkvar.sh nolu -DSC_SD_ABLATE_LU=1 ;  SC_LIB_PATH=var/libsc_nolu.so SC_DEBUG_SKIP_LU=1 python tools/phase_timing.py
+then reports the streaming phase alone (SC_DEBUG_SKIP_LU only tells sc_hk_step to skip the fix-up launch).
 """
 import os
 import sys
@@ -48,9 +50,6 @@ for occ in os.environ.get("OCC_LIST", "2").split(","):
     os.environ["SC_SD_OCC"] = occ
     t_full = timed(full)
     t_pref = timed(pref)
-    os.environ["SC_DEBUG_SKIP_LU"] = "1"
-    t_nolu = timed(full)
-    t_load = timed(pref)
-    del os.environ["SC_DEBUG_SKIP_LU"]
-    print(f"D={DIM} n={n} occ={occ}: full step {t_full:.3f} ms ({ab / t_full / 1e6:.0f} GB/s algorithmic) | without elimination "
-          f"{t_nolu:.3f} ms | prefactor only (load+mat+LU) {t_pref:.3f} ms | load+mat only {t_load:.3f} ms", flush=True)
+    what = "WITHOUT elimination" if os.environ.get("SC_DEBUG_SKIP_LU") else "full"
+    print(f"D={DIM} n={n} occ={occ} [{what}]: step {t_full:.3f} ms ({ab / t_full / 1e6:.0f} GB/s algorithmic) | "
+          f"prefactor-only launch (no RK4 / stores) {t_pref:.3f} ms", flush=True)
