@@ -178,7 +178,7 @@ def config1(dev, n, steps):
                     "host_overhead_note": "eager: ~6 ctypes launches per step from Python; graph: one hipGraphLaunch per step"})
     k = _kernel_ms(prop, pot, dt, E0, steps, dev)
     nbytes = algorithmic_bytes_per_traj_step(D) * n
-    out.update({"kernel": "hk_step_w16_kernel<true>", "kernel_ms": k.get("hk_step"),
+    out.update({"kernel": "hk_step_sep16_kernel<8,true,MORSE> (four trajectories per wavefront)", "kernel_ms": k.get("hk_step"),
                 "roofline": {"bound": "hbm", "achieved": nbytes / (k["hk_step"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": nbytes / (k["hk_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}})
     return out

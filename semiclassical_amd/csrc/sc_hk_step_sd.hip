@@ -41,6 +41,9 @@
 #ifndef SC_SD_XPREFETCH
 #define SC_SD_XPREFETCH 1  // request row slot 0 of the next trajectory before the last diagonal block of the elimination
 #endif
+#ifndef SC_SD_XPREFETCH_AHEAD
+#define SC_SD_XPREFETCH_AHEAD 1   // diagonal blocks of the elimination that run after the next trajectory's first requests
+#endif
 #ifndef SC_SD_ABLATE_LU
 #define SC_SD_ABLATE_LU 0  // 1: variant library without the elimination (streaming phase alone)
 #endif
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
             if (KB == (NR > 1 ? 1 : 0)) {            // behind the barrier of block 0 (NR = 1: the value is read after the last barrier)
                 if (NR > 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
             }
-            if (SC_SD_XPREFETCH && NR > 1 && KB == NR - 1) {
+            if (SC_SD_XPREFETCH && NR > 1 && KB == (NR - SC_SD_XPREFETCH_AHEAD > 1 ? NR - SC_SD_XPREFETCH_AHEAD : 1)) {
                 if (trn < A.st.n) {
                     first_requests(trn);
                 } else {                            // nothing follows: end the live ranges of the old values
@@ -491,6 +494,14 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     if (getenv("SC_NO_WAVE_KERNEL")) wave_kernel = false;
 #endif
     if (wave_kernel) {
+        bool packed = true;
+#ifdef SC_TUNING
+        if (getenv("SC_NO_SEP16")) packed = false;
+#endif
+        if (packed) {
+            const int rc = sc_launch_step_sep16(a, grid, s);      // four trajectories per wavefront
+            if (rc != 0) return rc < 0 ? rc : SC_OK;
+        }
         // partial sums: only the first `wg` entries are written, the energy guard adds sc_step_grid() of them
         const int64_t quads = (a.st.n + 3) / 4;
         const int wg = (int)(quads < 2048 ? quads : 2048);
