@@ -286,7 +286,9 @@ def launch_check():
     if world > 1:
         dist.all_reduce(t)
     assert "semiclassical_amd._lib" not in sys.modules
-    print(json.dumps({"rank": rank, "world": world, "local_rank": local, "sum": float(t.item())}), flush=True)
+    # one write per line: the ranks share the parent's stdout, print() would emit text and newline separately
+    sys.stdout.write(json.dumps({"rank": rank, "world": world, "local_rank": local, "sum": float(t.item())}) + "\n")
+    sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
