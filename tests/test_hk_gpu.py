@@ -441,3 +441,22 @@ def test_trajectory_cursor_and_static_assignment_agree(D, n):
         ref.step(opot, dt)
     assert cases.rel_err(cnp(a.y)[:, pick.numpy()], ref.y.numpy()) < 1e-10
     assert cases.rel_err(cnp(a._c2)[pick.numpy()], ref.c2.numpy()) < 1e-9
+
+
+def test_trajectory_cursor_under_graph_replay():
+    """the cursor is zeroed by a memset inside sc_hk_step: captured into the HIP graph of run(use_graph=True), it must be
+    reset on every replay (n > 1024 trajectories, D = 33: eager loop and graph replay give identical results)"""
+    import bench
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    D, n, nt = 33, 2200, 7
+    omega, chi, nac, q0, _ = bench.as60_model(D)
+    G, dt, E0 = torch.diag(omega), 4.0, float(0.5 * omega.sum())
+    out = []
+    for use_graph in (False, True):
+        prop = PR.HermanKlukPropagator(G, G, device="cuda")
+        prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(3))
+        c, k = prop.run(P.MorsePotential(omega, chi.clone(), nac), dt, nt, E0, use_graph=use_graph)
+        out.append((c, k, prop._c2.clone(), prop._qp.clone()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
