@@ -82,13 +82,14 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int GDML_CH) {
     L.P = f;    f += GDML_CH * L.XP;
     L.Qn = f;   f += GDML_CH * L.XP;
     L.Z = f;    f += GDML_CH * L.XP;
+    if ((f - base) & 1) ++f;           // 16-byte aligned: the stage is filled by 16-byte LDS-DMA loads
     L.stage = f;                       // [2][2][GDML_CH][Dd]: two buffers of a chunk's rows of xs_train, then of jx_alphas
     return L;
 }
 
 size_t gdml_lds_doubles_ch(int N, int Dd, int GDML_CH) {
     return 32 + 3 * N + 5 * (size_t)Dd + 4 * GDML_CH + 3 * N + (N & 1) + 9 * N + (N & 1) + 3 * (size_t)GDML_CH * gdml_xp(N) +
-           2 * 2 * (size_t)GDML_CH * Dd;
+           2 * 2 * (size_t)GDML_CH * Dd + 1;       // + 1: alignment pad of the stage
 }
 size_t gdml_lds_doubles(int N, int Dd) { return gdml_lds_doubles_ch(N, Dd, gdml_ch(N)); }
 
