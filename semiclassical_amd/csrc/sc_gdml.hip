@@ -155,7 +155,9 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
 #pragma unroll
     for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
         acc[sl] = (d4){0.0, 0.0, 0.0, 0.0};
-        const int t = wave + sl * nw;
+        // a slot beyond the last tile repeats the last tile (its accumulator is never written out): the matrix-core
+        // phase below has no branches
+        const int t = min(__builtin_amdgcn_readfirstlane(wave) + sl * nw, ntiles - 1);
         int c = 0;
         while ((c + 1) * (c + 2) / 2 <= t) ++c;
         tr_[sl] = t - c * (c + 1) / 2; tc_[sl] = c;
@@ -304,18 +306,29 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);             // this wavefront's part of chunk k + 1 has landed
         __syncthreads();
-        // (5) [XJ ; -e AJ]^T [Z ; XJ] of the chunk on the matrix cores
+        // (5) [XJ ; -e AJ]^T [Z ; XJ] of the chunk on the matrix cores: all operands of the wavefront's tiles are requested
+        //     first, then the MFMAs of the tiles run interleaved (one block, no wait between the products)
 #ifndef GDML_ABLATE_MFMA
+        {
+            constexpr int KS = GDML_CH / 4;
+            double oa[GDML_MAX_TILES][KS][2], ob[GDML_MAX_TILES][KS][2];
 #pragma unroll
-        for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
-            if (wave + sl * nw >= ntiles) continue;               // wave-uniform
-            const double *ar = L.P + rg * XP + 16 * tr_[sl] + li, *bc = L.Z + rg * XP + 16 * tc_[sl] + li;
-            const double *aq = L.Qn + rg * XP + 16 * tr_[sl] + li, *bp = L.P + rg * XP + 16 * tc_[sl] + li;
+            for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
+                const double *ar = L.P + rg * XP + 16 * tr_[sl] + li, *bc = L.Z + rg * XP + 16 * tc_[sl] + li;
+                const double *aq = L.Qn + rg * XP + 16 * tr_[sl] + li, *bp = L.P + rg * XP + 16 * tc_[sl] + li;
 #pragma unroll
-            for (int ks = 0; ks < GDML_CH / 4; ++ks) {
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[4 * ks * XP], bc[4 * ks * XP], acc[sl], 0, 0, 0);
-                acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[4 * ks * XP], bp[4 * ks * XP], acc[sl], 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    oa[sl][ks][0] = ar[4 * ks * XP]; ob[sl][ks][0] = bc[4 * ks * XP];
+                    oa[sl][ks][1] = aq[4 * ks * XP]; ob[sl][ks][1] = bp[4 * ks * XP];
+                }
             }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int w = 0; w < 2; ++w)
+#pragma unroll
+                    for (int sl = 0; sl < GDML_MAX_TILES; ++sl)
+                        acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[sl][ks][w], ob[sl][ks][w], acc[sl], 0, 0, 0);
         }
 #endif
     }
