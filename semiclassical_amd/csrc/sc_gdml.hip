@@ -202,6 +202,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     double sx[MPT][3], sa3[MPT][3];
     // (1) row reductions of the training points this wavefront owns in the chunk at m0: d_m^2 = |x - xs_m|^2,
     //     XA_m = (x - xs_m) . A_m (lanes over the descriptor), then the scalars e_m, f_m, w_m (gdml_predictor.py:150-170)
+    const double iq2 = 1.0 / (q * q);
     auto row_scalars = [&](int m0, const double *sxs, const double *sal) {
         for (int mm = wave; mm < min(GDML_CH, Mt - m0); mm += nw) {
             double s2 = 0.0, sa = 0.0;
@@ -219,10 +220,21 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
 #ifdef GDML_ABLATE_TAIL
                 const double dist = 1.0 + s2, e = 1.0 - q * dist;
 #else
-                const double dist = sqrt(s2), e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
+                // 1/d from the hardware reciprocal square root + two Newton steps (full fp64 accuracy), d = s2 / d with one
+                // correction: this serial tail sits between the row reductions and the chunk's first barrier, and sqrt
+                // plus two fp64 divisions were two thirds of it
+                double rd = __builtin_amdgcn_rsq(s2);
+                rd = fma(fma(-0.5 * s2 * rd, rd, 0.5), rd, rd);
+                rd = fma(fma(-0.5 * s2 * rd, rd, 0.5), rd, rd);
+                double dist = s2 * rd;
+                dist = fma(fma(-dist, dist, s2), 0.5 * rd, dist);
+                const double e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
 #endif
-                const double f = e * (1.0 + q * dist) / (q * q);
-                L.fm[mm] = f; L.em[mm] = e; L.wm[mm] = e * sa * q / dist; L.ea[mm] = e * sa;
+                const double f = e * (1.0 + q * dist) * iq2;
+#ifdef GDML_ABLATE_TAIL
+                const double rd = 1.0;
+#endif
+                L.fm[mm] = f; L.em[mm] = e; L.wm[mm] = e * sa * q * rd; L.ea[mm] = e * sa;
                 esum += f * sa; ssum += e * sa;
             }
         }
