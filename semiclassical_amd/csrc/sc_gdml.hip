@@ -203,44 +203,44 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     // (1) row reductions of the training points this wavefront owns in the chunk at m0: d_m^2 = |x - xs_m|^2,
     //     XA_m = (x - xs_m) . A_m (lanes over the descriptor), then the scalars e_m, f_m, w_m (gdml_predictor.py:150-170)
     const double iq2 = 1.0 / (q * q);
-    auto row_scalars = [&](int m0, const double *sxs, const double *sal) {
-        for (int mm = wave; mm < min(GDML_CH, Mt - m0); mm += nw) {
-            double s2 = 0.0, sa = 0.0;
+    // Branch-free: a wavefront without a training point in this chunk reduces the last row again and drops the result, and
+    // every lane evaluates the scalar tail (the sums are wave-uniform), so that the gathers of (2) -- issued between the
+    // reductions and the tail -- fill the latency of its dependent chain (rsq, Newton steps, exp).
+    auto row_scalars = [&](int m0, const double *sxs, const double *sal, auto &&between) {
+        const int mm = min(wave, GDML_CH - 1);
+        const bool has = wave < min(GDML_CH, Mt - m0);
+        double s2 = 0.0, sa = 0.0;
 #ifdef GDML_ABLATE_ROWRED
-            for (int d = lane; d < 64; d += 64) {
+        for (int d = lane; d < 64; d += 64) {
 #else
-            for (int d = lane; d < Dd; d += 64) {
+        for (int d = lane; d < Dd; d += 64) {
 #endif
-                const double xd = L.x[d] - sxs[mm * Dd + d];
-                s2 = fma(xd, xd, s2);
-                sa = fma(xd, sal[mm * Dd + d], sa);
-            }
-            s2 = wave_sum(s2); sa = wave_sum(sa);
-            if (lane == 0) {
+            const double xd = L.x[d] - sxs[mm * Dd + d];
+            s2 = fma(xd, xd, s2);
+            sa = fma(xd, sal[mm * Dd + d], sa);
+        }
+        s2 = wave_sum(s2); sa = wave_sum(sa);
+        between();
 #ifdef GDML_ABLATE_TAIL
-                const double dist = 1.0 + s2, e = 1.0 - q * dist;
+        const double dist = 1.0 + s2, e = 1.0 - q * dist, rd = 1.0;
 #else
-                // 1/d from the hardware reciprocal square root + two Newton steps (full fp64 accuracy), d = s2 / d with one
-                // correction: this serial tail sits between the row reductions and the chunk's first barrier, and sqrt
-                // plus two fp64 divisions were two thirds of it
-                double rd = __builtin_amdgcn_rsq(s2);
-                rd = fma(fma(-0.5 * s2 * rd, rd, 0.5), rd, rd);
-                rd = fma(fma(-0.5 * s2 * rd, rd, 0.5), rd, rd);
-                double dist = s2 * rd;
-                dist = fma(fma(-dist, dist, s2), 0.5 * rd, dist);
-                const double e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
+        // 1/d from the hardware reciprocal square root + two Newton steps (full fp64 accuracy), d = s2 / d with one
+        // correction (sqrt plus two fp64 divisions were two thirds of this serial tail)
+        double rd = __builtin_amdgcn_rsq(s2);
+        rd = fma(fma(-0.5 * s2 * rd, rd, 0.5), rd, rd);
+        rd = fma(fma(-0.5 * s2 * rd, rd, 0.5), rd, rd);
+        double dist = s2 * rd;
+        dist = fma(fma(-dist, dist, s2), 0.5 * rd, dist);
+        const double e = (1.0 / 3.0) * q * q * q * q * exp(-q * dist);
 #endif
-                const double f = e * (1.0 + q * dist) * iq2;
-#ifdef GDML_ABLATE_TAIL
-                const double rd = 1.0;
-#endif
-                L.fm[mm] = f; L.em[mm] = e; L.wm[mm] = e * sa * q * rd; L.ea[mm] = e * sa;
-                esum += f * sa; ssum += e * sa;
-            }
+        const double f = e * (1.0 + q * dist) * iq2;
+        if (has && lane == 0) {
+            L.fm[mm] = f; L.em[mm] = e; L.wm[mm] = e * sa * q * rd; L.ea[mm] = e * sa;
+            esum += f * sa; ssum += e * sa;
         }
     };
     // (2) J^T xs_m, J^T A_m of this thread's atom for its two training points (rows beyond a partial chunk are zero)
-    const int fm_row = fm_active ? MPT * fm_mh : 0, tri = fm_at * (fm_at - 1) / 2;   // threads without a role never gather
+    const int fm_row = fm_active ? MPT * fm_mh : 0, tri = fm_at * (fm_at - 1) / 2;   // threads without a role gather rows 0.., unused
     int pidx[QN];
 #pragma unroll
     for (int cc = 0; cc < QN; ++cc) {
@@ -283,9 +283,12 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         const int mc = min(GDML_CH, Mt - m0);
         const double *sxs = L.stage + buf * 2 * GDML_CH * Dd, *sal = sxs + GDML_CH * Dd;
         if (m0 + GDML_CH < Mt) stage_chunk(m0 + GDML_CH, buf ^ 1);
-        row_scalars(m0, sxs, sal);
         gather_begin();
-        if (fm_active) sfor<0, QN>([&](auto ccc) { gather_partner(ccc, sxs, sal); });
+        auto gathers = [&] { sfor<0, QN>([&](auto ccc) { gather_partner(ccc, sxs, sal); }); };
+        // four wavefronts: gathers between the row reductions and the scalar tail (coumarin 3.50 -> 3.35 ms per stage launch);
+        // eight wavefronts: after the tail (the interleaved order costs the larger kernel 28 more spilled registers)
+        if (THREADS == 256) row_scalars(m0, sxs, sal, gathers);
+        else { row_scalars(m0, sxs, sal, [] {}); gathers(); }
         gather_end();
         __syncthreads();
         // (3) gradient terms of the chunk, (4) operand rows of the chunk
