@@ -246,7 +246,11 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     for (int cc = 0; cc < QN; ++cc) {
         // position of pair (a, c) in a descriptor row; partners outside the molecule (and c = a) have coef = 0
         const int c = min(QN * fm_q + cc, N - 1);
+#ifdef GDML_TEST_NOCONFLICT
+        pidx[cc] = (tid & 31) + 32 * cc;      // experiment: conflict-free addresses (wrong results)
+#else
         pidx[cc] = c < fm_at ? tri + c : (c > fm_at ? c * (c - 1) / 2 + fm_at : 0);
+#endif
     }
     auto gather_begin = [&]() {
 #pragma unroll
