@@ -1,6 +1,7 @@
 // Coherent-state overlaps, non-adiabatic coupling factors and the per-step reduction into C_auto / k_ic.
 //
-// One wavefront per trajectory (lane = mode), grid-stride.  Reference semantics reproduced:
+// Lane = mode, grid-stride over trajectories (overlap / nac kernels: one per wavefront pass; correlate: 16).  Reference
+// semantics reproduced:
 //   <q,p,Gbra|qk,pk,Gket>                         semiclassical/propagators.py:181-240
 //   C_qp = conj(vt) vi (signs c) exp(iS/hbar)     semiclassical/propagators.py:784-807
 //   Monte-Carlo weight 1/(n probi (2 pi hbar)^D)  semiclassical/propagators.py:837
@@ -102,25 +103,37 @@ struct CorrArgs {
     double *cq_out, *kq_out, *partials;
 };
 
+// A wavefront takes 16 consecutive trajectories: their exponent sums are reduced one after the other (lane = mode) and
+// parked in lanes 0..15, then those 16 lanes evaluate the scalar tails -- complex exp, sqrt, the phase, the weight --
+// side by side.  (One trajectory per pass left 63 lanes idle during a tail that is longer than the reductions.)
 __global__ __launch_bounds__(256) void hk_correlate_kernel(CorrArgs A) {
     extern __shared__ double smem[];
     __shared__ double wsum[4][4];
+    constexpr int B = 16;
     const int D = A.st.dim, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     double *dvec = smem + (size_t)wave * 2 * D;
     double acc[4] = {0, 0, 0, 0};
-    for (int64_t tr = (int64_t)blockIdx.x * nw + wave; tr < A.st.n; tr += (int64_t)gridDim.x * nw) {
-        const double *qp = A.st.qp + tr * 2 * D;
-        double sA, sB, sP, sC, sR = 0, sG = 0;
-        overlap_sums(A.oc, qp, dvec, sA, sB, sP, sC);
-        if (A.has_nac) {
-            for (int a = lane; a < D; a += 64) {
-                sR = fma(A.nc.q0[a] - qp[a], A.nc.rn[a], sR);
-                sG = fma(qp[D + a] - A.nc.p0[a], A.nc.gn[a], sG);
+    const int64_t n = A.st.n, ntask = (n + B - 1) / B;
+    for (int64_t task = (int64_t)blockIdx.x * nw + wave; task < ntask; task += (int64_t)gridDim.x * nw) {
+        const int64_t base = task * B;
+        const int cnt = (int)(n - base < B ? n - base : B);
+        double mA = 0, mB = 0, mP = 0, mC = 0, mR = 0, mG = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const double *qp = A.st.qp + (base + j) * 2 * D;
+            double sA, sB, sP, sC, sR = 0, sG = 0;
+            overlap_sums(A.oc, qp, dvec, sA, sB, sP, sC);
+            if (A.has_nac) {
+                for (int a = lane; a < D; a += 64) {
+                    sR = fma(A.nc.q0[a] - qp[a], A.nc.rn[a], sR);
+                    sG = fma(qp[D + a] - A.nc.p0[a], A.nc.gn[a], sG);
+                }
+                sR = wave_sum(sR); sG = wave_sum(sG);
             }
-            sR = wave_sum(sR); sG = wave_sum(sG);
+            if (lane == j) { mA = sA; mB = sB; mP = sP; mC = sC; mR = sR; mG = sG; }
         }
-        if (lane == 0) {
-            const cplx vt = overlap_value(A.oc, sA, sB, sP, sC);
+        if (lane < cnt) {
+            const int64_t tr = base + lane;
+            const cplx vt = overlap_value(A.oc, mA, mB, mP, mC);
             const cplx c = c_scale(c_sqrt(((const cplx *)A.st.c2)[tr]), A.st.sgn[tr]);
             const cplx ph = c_exp(c_make(0.0, A.st.act[tr] / SC_HBAR));
             const double w = 1.0 / (A.mc_norm * A.probi[tr]);
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(256) void hk_correlate_kernel(CorrArgs A) {
             acc[0] += cq.x; acc[1] += cq.y;
             if (A.cq_out) ((cplx *)A.cq_out)[tr] = cq;
             if (A.has_nac) {
-                const cplx nacQ = c_make(A.nc.n2 + sR, -(A.nc.p0n1 + sG) / SC_HBAR);
+                const cplx nacQ = c_make(A.nc.n2 + mR, -(A.nc.p0n1 + mG) / SC_HBAR);
                 cplx kq = c_mul(c_mul(nacQ, ((const cplx *)A.nacq)[tr]), cq);
                 kq = c_scale(kq, 1.0 / (SC_HBAR * SC_HBAR));
                 acc[2] += kq.x; acc[3] += kq.y;
@@ -137,6 +150,8 @@ __global__ __launch_bounds__(256) void hk_correlate_kernel(CorrArgs A) {
             }
         }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);      // fixed order: deterministic
     if (lane == 0) { for (int i = 0; i < 4; ++i) wsum[wave][i] = acc[i]; }
     __syncthreads();
     if (threadIdx.x < 4) {
