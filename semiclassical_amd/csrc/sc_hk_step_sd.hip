@@ -46,7 +46,9 @@
 #endif
 // cache-policy bits of the block loads / stores (gfx942+: 1 = sc0, 2 = nt, 16 = sc1).  The blocks are touched once per step
 // and the state (11.5 GB) is far beyond every cache: non-temporal on BOTH sides is worth 2.6 % (4.69 -> 4.56 ms; loads
-// alone: nothing, stores alone: -0.5 %, scope bits: nothing)
+// alone: nothing, stores alone: -0.5 %, scope bits: nothing).  TILED layout only: there a wave instruction covers 512
+// contiguous bytes; on the 128-byte row segments of the row-major order (unaligned at D = 60) the same hint costs 45 %
+// (4.9 -> 7.2 ms), as it does on the 8-byte-per-lane row accesses of the small-D kernels
 #ifndef SC_SD_LOAD_AUX
 #define SC_SD_LOAD_AUX 2
 #endif
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                 const int vofs = voffset(ra, rb), base = tile_base(ra, rb), plane = plane_bytes(ra, rb);
 #pragma unroll
                 for (int pl = 0; pl < 4; ++pl) {
-                    const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, vofs, base + pl * plane, SC_SD_LOAD_AUX);
+                    const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, vofs, base + pl * plane, TILED ? SC_SD_LOAD_AUX : 0);
                     raw[ra & 1][pl][rb] = __hiloint2double((int)v.y, (int)v.x);
                 }
             }
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                     for (int pl = 0; pl < 4; ++pl) {
                         sc_v2u v;
                         v.x = (unsigned)__double2loint(out[pl]); v.y = (unsigned)__double2hiint(out[pl]);
-                        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vofs, base + pl * plane, SC_SD_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vofs, base + pl * plane, TILED ? SC_SD_STORE_AUX : 0);
                     }
                 }
                 const int bl = (16 * rb + tjl) & 63;
