@@ -228,7 +228,7 @@ def config5(dev, n, steps):
     prop = PR.HermanKlukPropagator(G, G, device=dev)
     prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(7))
     D, Dd = 3 * N, N * (N - 1) // 2
-    wall = _timed_loop(prop, pot, 2.0, 0.0, steps, dev, reps=2)
+    wall = _timed_loop(prop, pot, 2.0, 0.0, steps, dev, reps=3)
     k = _kernel_ms(prop, pot, 2.0, 0.0, steps, dev)
     # sGDML evaluation: three rank-M sums over (3N)^2 (6 M (3N)^2 flops), J^T products 2 x 2 M Dd 3 ... ; monodromy RK4 16 D^3
     stage_flops = (6 * M * D * D + 8 * M * Dd * 3 + 4 * M * Dd) * n
