@@ -275,11 +275,16 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
         const char *which = getenv("SC_FAST_KERNEL");
         if (which && which[0] == 'r') return sc_launch_step_rw(a, (hipStream_t)stream);
 #endif
+        // D <= 16: the small-D kernels pivot over the whole row (no flags, no cursor, no fix-up launch)
+        bool small = D <= 16;
+#ifdef SC_TUNING
+        if (getenv("SC_NO_WAVE_KERNEL")) small = false;      // the 256-thread kernel is forced: it needs flags and cursor
+#endif
         // flags[n]: trajectories flagged in this step, flags[n + 1]: trajectory cursor of the fast kernel
-        if (st->flags && hipMemsetAsync(st->flags + st->n, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
+        if (!small && st->flags && hipMemsetAsync(st->flags + st->n, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
             return sc_check_launch("sc_hk_step (flag counter)");
         const int rc = sc_launch_step_sd(a, (hipStream_t)stream);
-        if (rc != SC_OK || !st->flags || (dbg & 0x100)) return rc;
+        if (rc != SC_OK || !st->flags || small || (dbg & 0x100)) return rc;
         mode |= 0x200;      // fully pivoted fix-up of the trajectories the fast path flagged (normally none)
     }
     const size_t DD = (size_t)D * D, dp = hk->dprime;
