@@ -138,6 +138,12 @@ __global__ __launch_bounds__(256, 2) void hk_step_sep16_kernel(StepArgs A) {
         for (int g = 0; g < 16; ++g) s += red[g];
         A.epart[blockIdx.x] = s;
     }
+    // the energy guard adds sc_step_grid(n, D) = min(n, 4096) partials: workgroup 0 zeroes the ones no workgroup owns
+    // (instead of a memset launch in front of every step)
+    if (blockIdx.x == 0 && A.epart && STEP) {
+        const int entries = (int)(n < 4096 ? n : 4096);
+        for (int i = gridDim.x + tid; i < entries; i += 256) A.epart[i] = 0.0;
+    }
 }
 
 }  // namespace
@@ -151,8 +157,8 @@ int sc_launch_step_sep16(const StepArgs &a, int grid_entries, hipStream_t s) {
     const int wg = (int)(groups < 4096 ? groups : 4096);
     if (wg > grid_entries) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: %d energy partials, %d workgroups", grid_entries, wg);
     const bool step = (a.mode & 0xff) == 0;
-    if (a.epart && hipMemsetAsync(a.epart, 0, sizeof(double) * (size_t)grid_entries, s) != hipSuccess)
-        return sc_check_launch("sc_hk_step (partials)");
+    if (grid_entries != (int)(a.st.n < 4096 ? a.st.n : 4096))
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: %d energy partials, the kernel zeroes min(n, 4096)", grid_entries);
 #define SC_SEP16_K(DP_, KIND_)                                                                                      \
     do {                                                                                                            \
         if (step) hipLaunchKernelGGL((hk_step_sep16_kernel<DP_, true, KIND_>), dim3(wg), dim3(256), 0, s, a);       \
