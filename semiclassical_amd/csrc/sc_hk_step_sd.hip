@@ -55,6 +55,10 @@
 #ifndef SC_SD_STORE_AUX
 #define SC_SD_STORE_AUX 2
 #endif
+#ifndef SC_SD_DIRECT_P
+#define SC_SD_DIRECT_P 0     // 1: every thread loads the P_a of its rows itself (no LDS hand-over, one barrier less per
+                           // trajectory) -- measured 4.65 ms against 4.56 ms: rejected
+#endif
 #ifndef SC_SD_ABLATE_LU
 #define SC_SD_ABLATE_LU 0  // 1: variant library without the elimination (streaming phase alone)
 #endif
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     // NEXT trajectory are requested before the last diagonal block of the current elimination starts (most of the matrix
     // registers are dead by then): the first load round trip of a trajectory hides behind that block.
     double raw[2][4][NR];
+    double pv[2][4] = {{1.0, 0.0, 0.0, 1.0}, {1.0, 0.0, 0.0, 1.0}};     // SC_SD_DIRECT_P: P_a of the thread's row of slot ra = s (mod 2)
     double prv = 0.0;
     bool first = true;
     // Trajectories are handed out through a device-side cursor (sc_state.flags[n + 1], zeroed by sc_hk_step): the first
@@ -176,16 +181,28 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                     raw[ra & 1][pl][rb] = __hiloint2double((int)v.y, (int)v.x);
                 }
             }
+            if (SC_SD_DIRECT_P && do_step) {
+                // the four entries of P_a of this thread's row come straight from st.work (the 16 threads of a row read the
+                // same address; rows beyond D: offset beyond the resource, zeros): no LDS hand-over, no barrier
+                const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(A.st.work + t * 4 * (int64_t)Dl, 0, 32 * Dl, 0x00020000);
+                const unsigned vw = 16 * ra + til < Dl ? 8u * (unsigned)(16 * ra + til) : OOB;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rw, (int)vw, 8 * k * Dl, 0);
+                    pv[ra & 1][k] = __hiloint2double((int)v.y, (int)v.x);
+                }
+            }
         };
         auto first_requests = [&](int64_t t) {           // P_a and row slot 0 of trajectory t
-            if (do_step && pa < Dl) prv = A.st.work[(t * 4 + pk) * (int64_t)Dl + pa];
+            if (!SC_SD_DIRECT_P && do_step && pa < Dl) prv = A.st.work[(t * 4 + pk) * (int64_t)Dl + pa];
             load_slot(std::integral_constant<int, 0>(), t);
         };
         auto finish_slot = [&](auto rac) {
             constexpr int ra = decltype(rac)::value;
             const __amdgpu_buffer_rsrc_t rs = resource(tr);
             const int al = (16 * ra + til) & 63;
-            const double p11 = prop[al], p12 = prop[64 + al], p21 = prop[128 + al], p22 = prop[192 + al];
+            const double p11 = SC_SD_DIRECT_P ? pv[ra & 1][0] : prop[al], p12 = SC_SD_DIRECT_P ? pv[ra & 1][1] : prop[64 + al];
+            const double p21 = SC_SD_DIRECT_P ? pv[ra & 1][2] : prop[128 + al], p22 = SC_SD_DIRECT_P ? pv[ra & 1][3] : prop[192 + al];
             const double sta = scl[al], ista = scl[64 + al];
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         __builtin_amdgcn_sched_barrier(0);
         if (NR > 1 && SC_SD_DEPTH > 1) load_slot(std::integral_constant<int, (NR > 1 ? 1 : 0)>(), tr);
         __builtin_amdgcn_sched_barrier(0);
-        if (do_step) {
+        if (do_step && !SC_SD_DIRECT_P) {
             // every wave is past the previous trajectory's phase B (the elimination barriers lie in between), so prop
             // may be overwritten without another barrier
             if (pa < D) prop[64 * pk + pa] = prv;
@@ -258,9 +275,11 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                 } else {                            // nothing follows: end the live ranges of the old values
                     prv = 0.0;
 #pragma unroll
-                    for (int pl = 0; pl < 4; ++pl)
+                    for (int pl = 0; pl < 4; ++pl) {
+                        pv[0][pl] = 0.0;
 #pragma unroll
                         for (int rb = 0; rb < NR; ++rb) raw[0][pl][rb] = 0.0;
+                    }
                 }
             }
             if (!skip_lu) {
