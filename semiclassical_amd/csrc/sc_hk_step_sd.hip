@@ -65,6 +65,9 @@
 #ifndef SC_SD_FORCE_FIXUP
 #define SC_SD_FORCE_FIXUP 0
 #endif
+#ifndef SC_SD_KB0_BARRIER
+#define SC_SD_KB0_BARRIER wg_barrier       // no_barrier: see the comment at the elimination
+#endif
 #ifndef SC_SD_BLOCK_BARRIER
 #define SC_SD_BLOCK_BARRIER no_barrier     // wg_barrier: a workgroup barrier in front of every diagonal block
 #endif
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                 }
             }
             if (!skip_lu) {
-                if (KB == 0) eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, wg_barrier);
+                if (KB == 0) eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, SC_SD_KB0_BARRIER);
                 else eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, SC_SD_BLOCK_BARRIER);
             }
         });
