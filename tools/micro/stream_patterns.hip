@@ -136,6 +136,33 @@ __global__ __launch_bounds__(256, 4) void pat_e(double *mono, long n, int D) {
     }
 }
 
+// pattern E with non-temporal loads and stores
+__global__ __launch_bounds__(256, 4) void pat_e_nt(double *mono, long n, int D) {
+    const long blk = (long)D * D;
+    for (long tr = blockIdx.x; tr < n; tr += gridDim.x) {
+        double *M = mono + tr * 4 * blk;
+        for (long c0 = 0; c0 < blk; c0 += 256 * 4) {
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long c = c0 + u * 256 + threadIdx.x;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) v[p][u] = c < blk ? __builtin_nontemporal_load(&M[p * blk + c]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long c = c0 + u * 256 + threadIdx.x;
+                const double q = v[0][u] * 1.0000001 + v[2][u] * 1e-9, r = v[2][u] * 1.0000001 - v[0][u] * 1e-9;
+                const double s = v[1][u] * 1.0000001 + v[3][u] * 1e-9, t = v[3][u] * 1.0000001 - v[1][u] * 1e-9;
+                if (c < blk) {
+                    __builtin_nontemporal_store(q, &M[c]); __builtin_nontemporal_store(s, &M[blk + c]);
+                    __builtin_nontemporal_store(r, &M[2 * blk + c]); __builtin_nontemporal_store(t, &M[3 * blk + c]);
+                }
+            }
+        }
+    }
+}
+
 template <class F>
 static float timed(F f, int reps = 5) {
     hipEvent_t e0, e1;
@@ -180,6 +207,10 @@ int main(int argc, char **argv) {
         printf("C grid %4d                : %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
         t = timed([&] { hipLaunchKernelGGL(pat_a<4>, dim3(g), dim3(256), 0, 0, m, n, D, D); });
         printf("A grid %4d                : %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
+    }
+    for (int g : {1024, 4096, 8192}) {
+        t = timed([&] { hipLaunchKernelGGL(pat_e_nt, dim3(g), dim3(256), 0, 0, m, n, D); });
+        printf("E non-temporal, grid %4d  : %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
     }
     CHECK(hipMemcpy(m, m + 1, 8, hipMemcpyDeviceToDevice));
     hipFree(m);
