@@ -1,12 +1,12 @@
 // Fast path of the fused Herman-Kluk step for SEPARABLE potentials (diagonal Hessian) with DIAGONAL width
 // matrices and D <= 64 -- the anharmonic adiabatic-shift configurations of BASELINE.json.
 //
-// One 256-thread workgroup per trajectory, grid-stride.  Threads form a 16 x 16 grid (ti, tj); thread (ti, tj)
-// owns the elements (a, b) = (16*ra + ti, 16*rb + tj), ra, rb < NR = ceil(D/16), of all four monodromy blocks
-// and of the complex prefactor matrix.  Wave w holds the thread rows ti = w, w+4, w+8, w+12 (consecutive matrix
-// rows sit in DIFFERENT waves, which is what lets the elimination run as a pipeline); per slot a wave covers
-// four rows x 16 consecutive columns, i.e. every global access is a set of 128-byte row segments and the whole
-// 4*D*D*8-byte state of the trajectory is read once and written once.
+// One 256-thread workgroup per trajectory; 1024 persistent workgroups draw trajectories from a device-side cursor.
+// Threads form a 16 x 16 grid; thread (trow, tj) owns the elements (a, b) = (16*ra + trow, 16*rb + tj), ra, rb < NR =
+// ceil(D/16), of all four monodromy blocks and of the complex prefactor matrix.  Wave w holds the rows trow = 4w .. 4w+3
+// of every 16-row slot (contiguous memory in the tiled storage order: a wave instruction covers 512 bytes), while the
+// pivot ORDER inside a slot interleaves the waves (consecutive pivots sit in DIFFERENT waves, which is what lets the
+// elimination run as a pipeline).  The whole 4*D*D*8-byte state of the trajectory is read once and written once.
 //
 //   modes    (hk_modes_kernel, one wavefront per trajectory, lane = mode) RK4 of (q_a, p_a); S and <T+V> by wave
 //            reductions.  With a diagonal Hessian the monodromy elements (Mqq,Mpq)_ab and (Mqp,Mpp)_ab obey, for
@@ -15,16 +15,19 @@
 //                                                               (propagators.py:86-119, 313-383; potentials.py)
 //   phase B  every (a,b): (Mqq,Mpq)' = P_a (Mqq,Mpq), (Mqp,Mpp)' = P_a (Mqp,Mpp), store back, and form
 //            mat_ab = 1/2[ st_a/si_b Mqq + si_b/st_a Mpp - i hbar st_a si_b Mqp + i/hbar Mpq/(st_a si_b) ]
-//            in registers.  Element addresses are a wave-uniform base plus ONE per-thread 32-bit offset.
+//            in registers.  Raw buffer instructions: scalar tile / plane offset + ONE per-thread 32-bit offset;
+//            threads outside the matrix are cut off by the resource's range check (no branches).
 //                                                                            (propagators.py:969-986)
 //   phase C  c2 = det(mat) by Gaussian elimination with the matrix held in REGISTERS (NR*NR complex per
-//            thread).  Rows are eliminated in natural order; the pivot COLUMN of row k is chosen by magnitude
+//            thread).  Rows are eliminated in a fixed order; the pivot COLUMN of a row is chosen by magnitude
 //            among the live columns of the diagonal 16-column block (threshold pivoting: the 16 consecutive
 //            lanes that own the row search it with integer keys and DPP rotations).  Because pivots stay inside
 //            the diagonal block, finished row AND column blocks drop out statically.  The owner scales the row
 //            by 1/pivot and publishes it through LDS; the pivot-column entries a thread needs sit in its own
-//            16-lane group and are fetched with DPP row_newbcast.  Inside a block the four waves are NOT
-//            barrier-coupled: consumers poll a tag in the pivot record (see eliminate_block).
+//            16-lane group and are fetched with DPP row_newbcast.  The four waves are NOT barrier-coupled:
+//            consumers poll a tag in the pivot record (see eliminate_block); one barrier in front of the first
+//            block and one behind the last.  Pivot products (with the signs of the column choices) accumulate in
+//            LDS per row group; thread 0 multiplies them while the others stream the next trajectory.
 //            If the best in-block pivot is more than 16x smaller than the largest live entry of the row, the
 //            trajectory is flagged (sc_state.flags) and its determinant is recomputed by the fully pivoted
 //            LDS elimination of sc_hk_step.hip in the same stream (never observed for HK matrices so far; the
