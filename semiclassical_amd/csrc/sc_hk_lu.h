@@ -183,7 +183,9 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
 // polling the tag of pivrec[kt] (reading the record and the row in the same batch), fetches the pivot-column entries
 // with DPP, updates row slot KB first so that the 16 lanes owning row kt+1 can search and publish at once, and only
 // then does the rest of its rank-1 update.  The chain owner(kt) -> owner(kt+1) is the critical path; the bulk of
-// the update floats beside it.  One barrier per block protects the reuse of the 16 row buffers.
+// the update floats beside it.  `barrier()` in front of the block is the caller's choice: a wave owns every fourth
+// pivot step, so when step s is published every wave has consumed step s - 4, and a ring entry is rewritten 16 steps after
+// its last use -- only a caller whose waves may lag by a whole block (no pivot ownership in a partial block) needs it.
 // The pivot ORDER inside a block is kt = 0..15 with thread index ti = 4 j + w (j = 16-lane row of the wave, w = wave):
 // consecutive pivots are owned by different waves.  The matrix ROW a thread holds is trow = 4 w + j (a wave streams
 // four consecutive rows, see the kernel), i.e. pivot step kt eliminates row 4 (kt & 3) + (kt >> 2) of the block; steps
