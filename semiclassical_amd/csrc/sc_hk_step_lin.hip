@@ -18,6 +18,10 @@
 #include "sc_common.h"
 #include "sc_row16.h"
 
+#ifndef SC_LIN_OCC
+#define SC_LIN_OCC 2      // waves per SIMD the kernel is compiled for
+#endif
+
 namespace {
 
 template <int D, int DP, bool DIAG>
@@ -29,7 +33,7 @@ struct LinLayout {
 };
 
 template <int D, int DP, bool DIAG>
-__global__ __launch_bounds__(256, 2) void hk_step_lin_kernel(StepArgs A) {
+__global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A) {
     typedef LinLayout<D, DP, DIAG> L;
     constexpr int W = 2 * D, DD = D * D, N = DIAG ? D : DP;
     extern __shared__ double2 smem2[];
