@@ -132,7 +132,7 @@ def test_gdml_30_atoms_matches_oracle():
     assert dy < TOL30[3] and dc2 < TOL30[4]
 
 
-@pytest.mark.parametrize("N,M", [(5, 37), (12, 50), (19, 61), (21, 44), (24, 83), (28, 70), (32, 45), (32, 3)])
+@pytest.mark.parametrize("N,M", [(5, 37), (12, 50), (19, 61), (21, 44), (22, 40), (24, 83), (28, 70), (31, 29), (32, 45), (32, 3)])
 def test_gdml_launch_shapes_and_partial_chunks(N, M):
     """every instantiation of the sGDML kernels (4 or 8 wavefronts per geometry, 4 or 8 training points per chunk, the
     partner-coefficient counts of 8 ... 32 atoms) with a training-set size that leaves a partial last chunk: E, grad,
