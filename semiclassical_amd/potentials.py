@@ -34,7 +34,7 @@ class _DescriptorMixin(object):
         step matrix of the monodromy equations for it (``sc_potential.lin_prop``)"""
         cache = self.__dict__.setdefault("_desc_cache", {})
         key = str(device)
-        if dt is not None and self._step_matrix(0.0) is not None:
+        if dt is not None and self._has_step_matrix():
             base = self._descriptor(device)
             steps = cache[key][4]
             if dt not in steps:
@@ -65,6 +65,9 @@ class _DescriptorMixin(object):
     def _step_matrix(self, dt):
         """None: the Hessian depends on the position.  Constant-Hessian potentials return Phi(dt) (2D x 2D)."""
         return None
+
+    def _has_step_matrix(self):
+        return False
 
     def _invalidate_descriptor(self):
         self.__dict__.pop("_desc_cache", None)
@@ -247,7 +250,7 @@ class MolecularHarmonicPotential(_MolecularPotentialBase):
         reference propagators.py:342-357 with a constant Hessian) is the product with
         Phi = 1 + hG + (hG)^2/2 + (hG)^3/6 + (hG)^4/24: the four stages of propagators.py:86-119 written out"""
         D = self._dim
-        if D > 16:
+        if not self._has_step_matrix():
             return None              # the kernel that takes Phi holds D <= 16
         G = np.zeros((2 * D, 2 * D), dtype=np.longdouble)
         G[:D, D:] = np.diag(1.0 / self._masses.numpy().astype(np.longdouble))
@@ -255,6 +258,9 @@ class MolecularHarmonicPotential(_MolecularPotentialBase):
         hG, one = np.longdouble(dt) * G, np.eye(2 * D, dtype=np.longdouble)
         phi = one + hG @ (one + hG @ (one + hG @ (one + hG / 4) / 3) / 2)
         return np.ascontiguousarray(phi.astype(np.float64))
+
+    def _has_step_matrix(self):
+        return self._dim <= 16
 
     def harmonic_approximation(self, r):
         dev = r.device
