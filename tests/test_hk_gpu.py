@@ -209,6 +209,22 @@ def test_weak_pivot_fallback():
     assert int(prop._flags[-2].item()) == prop.ntraj           # ... which was needed for every trajectory
 
 
+def test_singular_prefactor_matrix_gives_zero_determinant():
+    """a zero row in every monodromy block (row 7) makes the prefactor matrix singular for every second trajectory: the
+    register elimination meets a zero pivot (flag bit in LDS, no determinant carried in registers) and must return
+    c2 = 0 exactly -- as torch.det of the oracle does up to rounding -- while the other trajectories are untouched"""
+    def blocks(d, n):
+        gen = torch.Generator().manual_seed(8)
+        out = [torch.eye(d).unsqueeze(2).expand(-1, -1, n).clone() + 0.1 * torch.randn(d, d, n, generator=gen) for _ in range(4)]
+        for blk in out:
+            blk[7, :, ::2] = 0.0
+        return out
+    got, want, prop = _prefactor_of_state("hk_as60", blocks)
+    assert np.all(got[::2] == 0.0)
+    assert np.max(np.abs(want[::2])) < 1e-10 * np.max(np.abs(want[1::2]))
+    assert np.max(np.abs(got[1::2] - want[1::2]) / np.abs(want[1::2])) < 1e-9
+
+
 def test_unsupported_sizes_fail_loudly():
     """no silent fallback: what the kernels cannot hold is refused with the C-ABI's error text"""
     from semiclassical_amd import propagators as PR
