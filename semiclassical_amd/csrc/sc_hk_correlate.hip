@@ -118,18 +118,42 @@ __global__ __launch_bounds__(256) void hk_correlate_kernel(CorrArgs A) {
         const int64_t base = task * B;
         const int cnt = (int)(n - base < B ? n - base : B);
         double mA = 0, mB = 0, mP = 0, mC = 0, mR = 0, mG = 0;
-        for (int j = 0; j < cnt; ++j) {
-            const double *qp = A.st.qp + (base + j) * 2 * D;
-            double sA, sB, sP, sC, sR = 0, sG = 0;
-            overlap_sums(A.oc, qp, dvec, sA, sB, sP, sC);
-            if (A.has_nac) {
-                for (int a = lane; a < D; a += 64) {
-                    sR = fma(A.nc.q0[a] - qp[a], A.nc.rn[a], sR);
-                    sG = fma(qp[D + a] - A.nc.p0[a], A.nc.gn[a], sG);
+        if (A.oc.diag && D <= 64) {
+            // diagonal widths, one mode per lane: (q_a, p_a) of trajectory j + 1 are requested before the six wave sums of
+            // trajectory j run (the sums are a dependent DPP chain; the load latency hides behind it)
+            const bool own = lane < D;
+            const double ocA = own ? A.oc.A[lane] : 0.0, ocB = own ? A.oc.B[lane] : 0.0, ocC = own ? A.oc.C[lane] : 0.0;
+            const double qk = own ? A.oc.qk[lane] : 0.0, pk = own ? A.oc.pk[lane] : 0.0;
+            const double nq0 = (own && A.has_nac) ? A.nc.q0[lane] : 0.0, np0 = (own && A.has_nac) ? A.nc.p0[lane] : 0.0;
+            const double nrn = (own && A.has_nac) ? A.nc.rn[lane] : 0.0, ngn = (own && A.has_nac) ? A.nc.gn[lane] : 0.0;
+            const double *qp0 = A.st.qp + base * 2 * D;
+            double qn = own ? qp0[lane] : 0.0, pn = own ? qp0[D + lane] : 0.0;
+            for (int j = 0; j < cnt; ++j) {
+                const double q = qn, p = pn;
+                if (j + 1 < cnt) {
+                    const double *nx = A.st.qp + (base + j + 1) * 2 * D;
+                    qn = own ? nx[lane] : 0.0; pn = own ? nx[D + lane] : 0.0;
                 }
-                sR = wave_sum(sR); sG = wave_sum(sG);
+                const double dq = qk - q, dpp = pk - p;
+                double sA = wave_sum(dq * ocA * dq), sB = wave_sum(dpp * ocB * dpp), sP = wave_sum(pk * dq), sC = wave_sum(dq * ocC * dpp);
+                double sR = 0, sG = 0;
+                if (A.has_nac) { sR = wave_sum((nq0 - q) * nrn); sG = wave_sum((p - np0) * ngn); }
+                if (lane == j) { mA = sA; mB = sB; mP = sP; mC = sC; mR = sR; mG = sG; }
             }
-            if (lane == j) { mA = sA; mB = sB; mP = sP; mC = sC; mR = sR; mG = sG; }
+        } else {
+            for (int j = 0; j < cnt; ++j) {
+                const double *qp = A.st.qp + (base + j) * 2 * D;
+                double sA, sB, sP, sC, sR = 0, sG = 0;
+                overlap_sums(A.oc, qp, dvec, sA, sB, sP, sC);
+                if (A.has_nac) {
+                    for (int a = lane; a < D; a += 64) {
+                        sR = fma(A.nc.q0[a] - qp[a], A.nc.rn[a], sR);
+                        sG = fma(qp[D + a] - A.nc.p0[a], A.nc.gn[a], sG);
+                    }
+                    sR = wave_sum(sR); sG = wave_sum(sG);
+                }
+                if (lane == j) { mA = sA; mB = sB; mP = sP; mC = sC; mR = sR; mG = sG; }
+            }
         }
         if (lane < cnt) {
             const int64_t tr = base + lane;
