@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        10
+#define SC_ABI_VERSION        11
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -198,6 +198,18 @@ int sc_mono_convert(const sc_state *st, int32_t to_layout, void *stream);
 /* y (rows = 2D+4D^2+1, n) with n fastest  <->  engine layout.   reference propagators.py:329-334, 581 */
 int sc_state_from_reference(const double *y, const sc_state *st, void *stream);
 int sc_state_to_reference(const sc_state *st, double *y, void *stream);
+
+/* Initial conditions sampled ON THE DEVICE, replaces the sampling half of HermanKlukPropagator.initial_conditions
+ * (propagators.py:537-566: xi ~ N(0,1) of shape (2d', n), zi = z0 + iLz^T xi, probi = detLz/(2 pi)^D exp(-|xi|^2/2))
+ * and, with init_state != 0, the construction of y(0) (:581-603: q, p = zi, S = 0, Mqq = Mpp = 1; also c2 = 1,
+ * sgn = 1; st->mono is written ROW-MAJOR).
+ *   ilz   [2d'][2D] row-major = block_diag(iLq, iLp) (:506-528), z0 [2D] = (q0, p0), prob0 = detLz/(2 pi)^D
+ *   zi_t  [n][2D] out, probi [n] out, xi_out [n][2d'] out or NULL (the deviates themselves)
+ * Deviates: Philox4x32-10 + Box-Muller; deviate j of the trajectory with GLOBAL index first + i depends only on
+ * (seed, subsequence, first + i, j) -- not on n, the launch shape or the rank that draws it.  d' <= 256. */
+int sc_sample_initial(const sc_state *st, const double *ilz, const double *z0, int32_t dprime, double prob0,
+                      uint64_t seed, uint64_t subsequence, int64_t first, int32_t init_state, double *zi_t,
+                      double *probi, double *xi_out, void *stream);
 
 /* One RK4 step of (q,p,Mqq,Mqp,Mpq,Mpp,S) followed by the HK prefactor and its sqrt-branch tracking,
  * fused per trajectory.  Replaces _rk4_step + EquationsOfMotion.f + potential.harmonic_approximation

@@ -72,7 +72,7 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 10              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 11              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 
@@ -87,6 +87,8 @@ SIGNATURES = {
     "sc_mono_convert": (C.c_int, [P(sc_state), C.c_int32, C.c_void_p]),
     "sc_state_from_reference": (C.c_int, [c_double_p, P(sc_state), C.c_void_p]),
     "sc_state_to_reference": (C.c_int, [P(sc_state), c_double_p, C.c_void_p]),
+    "sc_sample_initial": (C.c_int, [P(sc_state), c_double_p, c_double_p, C.c_int32, C.c_double, C.c_uint64, C.c_uint64,
+                                    C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     "sc_hk_step": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), C.c_double, C.c_int32,
                              c_double_p, C.c_void_p]),
     "sc_overlap": (C.c_int, [P(sc_overlap_consts), c_double_p, C.c_int64, c_double_p, C.c_void_p]),

@@ -68,9 +68,6 @@
 #ifndef SC_SD_FORCE_FIXUP
 #define SC_SD_FORCE_FIXUP 0
 #endif
-#ifndef SC_SD_KB0_BARRIER
-#define SC_SD_KB0_BARRIER wg_barrier       // no_barrier: see the comment at the elimination
-#endif
 #ifndef SC_SD_BLOCK_BARRIER
 #define SC_SD_BLOCK_BARRIER no_barrier     // wg_barrier: a workgroup barrier in front of every diagonal block
 #endif
@@ -103,6 +100,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         const bool in = tid < D;
         const double st = in ? A.hk.st[tid] : 1.0, si = in ? A.hk.si[tid] : 1.0;
         if (tid < 16) pivrec[tid].pad = 0;
+        if (tid < 2) { nextbuf[tid] = 0; weakbuf[tid] = 0; }      // never read before they are written (RESET BARRIER below); defined anyway
         scl[tid] = st; scl[64 + tid] = 1.0 / st; scl[128 + tid] = si; scl[192 + tid] = 1.0 / si;
         prop[tid] = 1.0; prop[64 + tid] = 0.0; prop[128 + tid] = 0.0; prop[192 + tid] = 1.0;
     }
@@ -263,16 +261,21 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         // kernel 148 B/lane of scratch and 30 % of its speed
         constexpr bool skip_lu = SC_SD_ABLATE_LU != 0;
         if (cursor && tl == 0) nextbuf[par] = drawn;
-        // Only block 0 starts behind a barrier (it also orders the resets above).  Later blocks need none: a wave
-        // owns every fourth pivot step, so when step s is published every wave has consumed step s - 4, and a row
-        // buffer is rewritten 16 steps after its last use.
+        // RESET BARRIER -- unconditional, in every variant of this kernel (with or without the elimination).  It orders
+        //   (a) thread 0's nextbuf[par] = drawn against the readfirstlane(nextbuf[par]) of every wave below: the value is
+        //       the next trajectory index and goes straight into resource(trn), an unordered read addresses memory
+        //       outside the state (the GPU memory fault of round 2's tuning build);
+        //   (b) the resets of *weak and detbuf[par] above against the owner lanes' read-modify-writes in the elimination;
+        //   (c) the previous trajectory's last uses of the pivot ring (rowbuf / pivrec) against block 0's first records.
+        // Later blocks need no barrier: a wave owns every fourth pivot step, so when step s is published every wave has
+        // consumed step s - 4, and a ring entry is rewritten 16 steps after its last use.
+        __syncthreads();
         auto wg_barrier = [] { __syncthreads(); };
         auto no_barrier = [] {};
-        (void)no_barrier;
+        (void)no_barrier; (void)wg_barrier;
         sfor<0, NR>([&](auto kbc) {
             constexpr int KB = decltype(kbc)::value;
-            if (KB == 0 && skip_lu) __syncthreads();   // elimination ablated: the barrier block 0 would have had
-            if (KB == (NR > 1 ? 1 : 0)) {            // behind the barrier of block 0 (NR = 1: the value is read after the last barrier)
+            if (KB == (NR > 1 ? 1 : 0)) {            // behind the RESET BARRIER (NR = 1: the value is read after the last barrier)
                 if (NR > 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
             }
             if (SC_SD_XPREFETCH && NR > 1 && KB == (NR - SC_SD_XPREFETCH_AHEAD > 1 ? NR - SC_SD_XPREFETCH_AHEAD : 1)) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                 }
             }
             if (!skip_lu) {
-                if (KB == 0) eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, SC_SD_KB0_BARRIER);
+                if (KB == 0) eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, no_barrier);   // the RESET BARRIER is its barrier
                 else eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, SC_SD_BLOCK_BARRIER);
             }
         });

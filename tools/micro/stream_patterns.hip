@@ -163,6 +163,83 @@ __global__ __launch_bounds__(256, 4) void pat_e_nt(double *mono, long n, int D) 
     }
 }
 
+
+// ---- round 3: is the in-place pattern the floor?  The same bytes read from one buffer and written to ANOTHER ----
+// pattern E out of place: reads src, writes dst (same thread -> address mapping, same launch shape)
+template <bool NT>
+__global__ __launch_bounds__(256, 4) void pat_e_oop(const double *src, double *dst, long n, int D) {
+    const long blk = (long)D * D;
+    for (long tr = blockIdx.x; tr < n; tr += gridDim.x) {
+        const double *M = src + tr * 4 * blk;
+        double *O = dst + tr * 4 * blk;
+        for (long c0 = 0; c0 < blk; c0 += 256 * 4) {
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long c = c0 + u * 256 + threadIdx.x;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) v[p][u] = c < blk ? (NT ? __builtin_nontemporal_load(&M[p * blk + c]) : M[p * blk + c]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long c = c0 + u * 256 + threadIdx.x;
+                const double q = v[0][u] * 1.0000001 + v[2][u] * 1e-9, r = v[2][u] * 1.0000001 - v[0][u] * 1e-9;
+                const double s = v[1][u] * 1.0000001 + v[3][u] * 1e-9, t = v[3][u] * 1.0000001 - v[1][u] * 1e-9;
+                if (c < blk) {
+                    if (NT) {
+                        __builtin_nontemporal_store(q, &O[c]); __builtin_nontemporal_store(s, &O[blk + c]);
+                        __builtin_nontemporal_store(r, &O[2 * blk + c]); __builtin_nontemporal_store(t, &O[3 * blk + c]);
+                    } else { O[c] = q; O[blk + c] = s; O[2 * blk + c] = r; O[3 * blk + c] = t; }
+                }
+            }
+        }
+    }
+}
+
+// plain copy, 16 B per lane, grid-stride over the whole array (the guide's "float4 copy" figure on THIS box)
+typedef double sc_d2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__global__ __launch_bounds__(256, 4) void copy16(const sc_d2 *src, sc_d2 *dst, long count) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i0 = (long)blockIdx.x * 256 * 4; i0 < count; i0 += stride) {
+        sc_d2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * 256 + threadIdx.x;
+            v[u] = i < count ? (NT ? __builtin_nontemporal_load(&src[i]) : src[i]) : sc_d2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * 256 + threadIdx.x;
+            if (i < count) { if (NT) __builtin_nontemporal_store(v[u], &dst[i]); else dst[i] = v[u]; }
+        }
+    }
+}
+
+// read only (sum to one value per thread, written once) and write only: the two halves of the stream on their own
+__global__ __launch_bounds__(256, 4) void read16(const double2 *src, double *out, long count) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    double acc = 0.0;
+    for (long i0 = (long)blockIdx.x * 256 * 4; i0 < count; i0 += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * 256 + threadIdx.x;
+            if (i < count) { const double2 v = src[i]; acc += v.x + v.y; }
+        }
+    }
+    if (acc == 12345.678) out[0] = acc;
+}
+__global__ __launch_bounds__(256, 4) void write16(double2 *dst, long count) {
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i0 = (long)blockIdx.x * 256 * 4; i0 < count; i0 += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * 256 + threadIdx.x;
+            if (i < count) dst[i] = make_double2(1.0, 2.0);
+        }
+    }
+}
+
 template <class F>
 static float timed(F f, int reps = 5) {
     hipEvent_t e0, e1;
@@ -211,6 +288,36 @@ int main(int argc, char **argv) {
     for (int g : {1024, 4096, 8192}) {
         t = timed([&] { hipLaunchKernelGGL(pat_e_nt, dim3(g), dim3(256), 0, 0, m, n, D); });
         printf("E non-temporal, grid %4d  : %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
+    }
+
+    // ---- round 3: out of place, same session ----
+    {
+        double *m2;
+        const size_t used = (size_t)n * 4 * D * D * 8;
+        CHECK(hipMalloc(&m2, used));
+        CHECK(hipMemset(m2, 0, used));
+        const long cnt = (long)(used / 16);
+        for (int g : {1024, 2048, 4096, 8192}) {
+            t = timed([&] { hipLaunchKernelGGL(pat_e, dim3(g), dim3(256), 0, 0, m, n, D); });
+            printf("E in place,      grid %4d : %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
+            t = timed([&] { hipLaunchKernelGGL(pat_e_oop<false>, dim3(g), dim3(256), 0, 0, m, m2, n, D); });
+            printf("E OUT of place,  grid %4d : %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
+            t = timed([&] { hipLaunchKernelGGL(pat_e_oop<true>, dim3(g), dim3(256), 0, 0, m, m2, n, D); });
+            printf("E OUT of place nt, grid %4d: %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
+            t = timed([&] { hipLaunchKernelGGL(copy16<false>, dim3(g), dim3(256), 0, 0, (const sc_d2 *)m, (sc_d2 *)m2, cnt); });
+            printf("plain 16-B copy, grid %4d : %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
+            t = timed([&] { hipLaunchKernelGGL(copy16<true>, dim3(g), dim3(256), 0, 0, (const sc_d2 *)m, (sc_d2 *)m2, cnt); });
+            printf("plain 16-B copy nt, grid %4d: %.3f ms  %.0f GB/s\n", g, t, gb / t * 1e3);
+        }
+        t = timed([&] { hipLaunchKernelGGL(copy16<false>, dim3(65536), dim3(256), 0, 0, (const sc_d2 *)m, (sc_d2 *)m2, cnt); });
+        printf("plain 16-B copy, grid 65536: %.3f ms  %.0f GB/s\n", t, gb / t * 1e3);
+        t = timed([&] { CHECK(hipMemcpyAsync(m2, m, used, hipMemcpyDeviceToDevice, 0)); });
+        printf("hipMemcpy D2D              : %.3f ms  %.0f GB/s\n", t, gb / t * 1e3);
+        t = timed([&] { hipLaunchKernelGGL(read16, dim3(4096), dim3(256), 0, 0, (const double2 *)m, m2, cnt); });
+        printf("read only  (11.52 GB)      : %.3f ms  %.0f GB/s\n", t, gb / 2 / t * 1e3);
+        t = timed([&] { hipLaunchKernelGGL(write16, dim3(4096), dim3(256), 0, 0, (double2 *)m2, cnt); });
+        printf("write only (11.52 GB)      : %.3f ms  %.0f GB/s\n", t, gb / 2 / t * 1e3);
+        CHECK(hipFree(m2));
     }
     CHECK(hipMemcpy(m, m + 1, 8, hipMemcpyDeviceToDevice));
     hipFree(m);

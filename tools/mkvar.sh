@@ -4,6 +4,4 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p var
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I include -I semiclassical_amd/csrc \
-    -DSC_TUNING -o var/libsc_$name.so "$@" semiclassical_amd/csrc/*.hip tools/variants/*.hip
-echo var/libsc_$name.so
+python -m semiclassical_amd.build --out var/libsc_$name.so -DSC_TUNING "$@" | tail -1
