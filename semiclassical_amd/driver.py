@@ -192,11 +192,22 @@ def run_semiclassical_dynamics(task, device='cuda'):
     if seed is not None:
         logger.warning("The random number generator should not be seeded manually unless for debugging!")
         torch.manual_seed(seed)
+    # Where the phase-space points are drawn (a key the reference does not have; it samples on its compute device,
+    # cli.py:392 -> propagators.py:537-539): "device" = sc_sample_initial (counter-based Philox keyed by the seed, one
+    # subsequence per repetition, nothing crosses PCIe), "host" = torch's CPU generator as in the reference's CPU runs.
+    sampling = task.get('sampling', 'device')
+    if sampling not in ('device', 'host'):
+        raise ValueError("'sampling' should be one of 'device' or 'host'")
+    device_seed = int(seed) if seed is not None else int.from_bytes(os.urandom(8), 'little')
 
     for repetition in range(repetitions):
         logger.info(f"*** Repetition {repetition + 1} ***")
         propagator = make_propagator(task, setup.Gamma_0, device)
-        propagator.initial_conditions(setup.q0, setup.p0, setup.Gamma_0, ntraj=per_batch)
+        if sampling == 'device':
+            propagator.initial_conditions(setup.q0, setup.p0, setup.Gamma_0, ntraj=per_batch, seed=device_seed,
+                                          subsequence=repetition)
+        else:
+            propagator.initial_conditions(setup.q0, setup.p0, setup.Gamma_0, ntraj=per_batch)
         autocorrelation, ic_correlation = propagate_batch(propagator, setup, dt, nt, times,
                                                           norm_every=task.get('calc_norm_every', 0))
         assert not np.isnan(autocorrelation).any(), f"encountered NaN's in autocorrelation : {autocorrelation}"

@@ -86,28 +86,50 @@ class HermanKlukPropagator(object):
         self._ntraj_norm = None
 
     # ------------------------------------------------------------------ initial conditions
-    def initial_conditions(self, q0, p0, Gamma_0, ntraj=5000, ntraj_total=None, generator=None):
+    def initial_conditions(self, q0, p0, Gamma_0, ntraj=5000, ntraj_total=None, generator=None, seed=None, subsequence=0,
+                           first_index=0):
         """Sample ``ntraj`` phase-space points from |<qi,pi,Gamma_i|q0,p0,Gamma_0>|^2 and reset the state.
 
-        The standard-normal deviates are drawn on the host with the same call the reference makes
-        (propagators.py:537-539), so on a given torch build ``torch.manual_seed(s)`` reproduces the
-        reference's CPU initial conditions.  ``ntraj_total`` (default ``ntraj``) is the N of the
-        Monte-Carlo weight 1/(N P(qi,pi)); a rank that owns one shard of a larger batch passes the
-        global count.
+        Two sources of the standard-normal deviates xi (reference propagators.py:537-539):
+
+        * default / ``generator``: drawn on the HOST with the call the reference makes, so on a given torch build
+          ``torch.manual_seed(s)`` reproduces the reference's CPU initial conditions (parity fixtures are made this way);
+        * ``seed`` (an integer): drawn ON THE DEVICE by ``sc_sample_initial`` (Philox4x32-10 + Box-Muller), together with
+          ``zi = z0 + iLz^T xi``, ``probi`` and the state of t = 0 -- nothing crosses PCIe.  Deviate j of the trajectory
+          with global index ``first_index + i`` depends only on ``(seed, subsequence, first_index + i, j)``: a rank that
+          owns one shard of a larger batch passes its first global index (same ensemble as one big batch) or its own
+          ``subsequence`` (an independent ensemble).
+
+        ``ntraj_total`` (default ``ntraj``) is the N of the Monte-Carlo weight 1/(N P(qi,pi)); a rank that owns one shard
+        of a larger batch passes the global count.
         """
         q0, p0, Gamma_0 = hostmath.as_f64(q0), hostmath.as_f64(p0), hostmath.as_f64(Gamma_0)
         assert Gamma_0.size() == self._Gi.size(), "Width parameter matrix Gamma_0 has wrong dimensions."
         assert hostmath.is_symmetric_non_negative(Gamma_0), "Gamma_0 has to be symmetric and positive semi-definite."
         d = q0.size()[0]
         U, iGi0, iLz, detLz, dprime = hostmath.sampling_matrices(self._Gi, Gamma_0)
+        z0 = torch.cat((q0, p0))
+        prob0 = detLz / (2 * np.pi) ** d
+        if seed is not None:
+            assert generator is None, "either a host generator or a device seed"
+            dev = self.device
+            self._begin_state(q0, p0, Gamma_0, U, iGi0, int(ntraj), ntraj_total)
+            self._zi_t = torch.empty((ntraj, 2 * d), dtype=F64, device=dev)
+            self.probi = torch.empty(ntraj, dtype=F64, device=dev)
+            ilz_d, z0_d = iLz.contiguous().to(dev), z0.to(dev)
+            check(lib.sc_sample_initial(self._state, ptr(ilz_d), ptr(z0_d), dprime, float(prob0), int(seed) & (2 ** 64 - 1),
+                                        int(subsequence) & (2 ** 64 - 1), int(first_index), 1, ptr(self._zi_t),
+                                        ptr(self.probi), None, self._stream()))
+            self.zi = self._zi_t.t()                   # the reference's (2D, n) attribute, as a view
+            self._finish_state((ilz_d, z0_d))
+            return
         if generator is None:
             xi = torch.distributions.Normal(torch.zeros(2 * dprime, dtype=F64),
                                             torch.ones(2 * dprime, dtype=F64)).sample((ntraj,)).T
         else:
             xi = torch.randn((ntraj, 2 * dprime), dtype=F64, generator=generator).T
-        z0 = torch.cat((q0, p0))
         zi = z0.unsqueeze(1) + torch.einsum('ji,jn->in', iLz, xi)
-        probi = detLz / (2 * np.pi) ** d * torch.exp(-0.5 * torch.einsum('in,in->n', xi, xi))
+        probi = prob0 * torch.exp(-0.5 * torch.einsum('in,in->n', xi, xi))
         self.set_initial_conditions(q0, p0, Gamma_0, zi, probi, ntraj_total=ntraj_total)
 
     def set_initial_conditions(self, q0, p0, Gamma_0, zi, probi, ntraj_total=None):
@@ -117,30 +139,44 @@ class HermanKlukPropagator(object):
         d, n = q0.size()[0], zi.shape[1]
         assert zi.shape[0] == 2 * d and probi.shape[0] == n
         U, iGi0, _, _, dprime = hostmath.sampling_matrices(self._Gi, Gamma_0)
+        self._begin_state(q0, p0, Gamma_0, U, iGi0, n, ntraj_total)
+        self.zi = torch.as_tensor(zi, dtype=F64).to(dev).contiguous()
+        self.probi = torch.as_tensor(probi, dtype=F64).to(dev).contiguous()
+        self._zi_t = self.zi.t().contiguous()                          # [n][2D]
+        self._qp.copy_(self._zi_t)
+        self._act.zero_()
+        self._mono.zero_()
+        torch.diagonal(self._mono[:, 0], dim1=1, dim2=2).fill_(1.0)
+        torch.diagonal(self._mono[:, 3], dim1=1, dim2=2).fill_(1.0)
+        self._c2.fill_(1.0)
+        self._sgn.fill_(1.0)
+        self._finish_state(None)
+
+    def _begin_state(self, q0, p0, Gamma_0, U, iGi0, n, ntraj_total):
+        """host constants + the (uninitialised) engine state of a batch of ``n`` trajectories"""
+        dev = self.device
+        d = q0.size()[0]
         self.dim, self.ntraj = d, n
         self._ntraj_norm = n if ntraj_total is None else int(ntraj_total)
         self._q0h, self._p0h, self._G0h, self._iGi0h = q0, p0, Gamma_0, iGi0
         self.q0, self.p0, self.Gamma_0 = q0.to(dev), p0.to(dev), Gamma_0.to(dev)
         self.U, self.iGi0 = U.to(dev), iGi0.to(dev)
-        self.zi = torch.as_tensor(zi, dtype=F64).to(dev).contiguous()
-        self.probi = torch.as_tensor(probi, dtype=F64).to(dev).contiguous()
-
         # ---- engine state (trajectory-major) ----
-        self._zi_t = self.zi.t().contiguous()                          # [n][2D]
-        self._qp = self._zi_t.clone()
-        self._act = torch.zeros(n, dtype=F64, device=dev)
-        self._mono = torch.zeros((n, 4, d, d), dtype=F64, device=dev)
-        eye = torch.eye(d, dtype=F64, device=dev)
-        self._mono[:, 0] = eye
-        self._mono[:, 3] = eye
-        self._c2 = torch.ones(n, dtype=C128, device=dev)
-        self._sgn = torch.ones(n, dtype=F64, device=dev)
+        self._qp = torch.empty((n, 2 * d), dtype=F64, device=dev)
+        self._act = torch.empty(n, dtype=F64, device=dev)
+        self._mono = torch.empty((n, 4, d, d), dtype=F64, device=dev)
+        self._c2 = torch.empty(n, dtype=C128, device=dev)
+        self._sgn = torch.empty(n, dtype=F64, device=dev)
         self._flags = torch.zeros(n + 2, dtype=torch.int32, device=dev)     # [n] = flagged count, [n + 1] = work cursor
         self._work = torch.zeros((n, 4, d), dtype=F64, device=dev)
         self._state = sc_state(n=n, dim=d, mono_layout=_lib.SC_MONO_ROWMAJOR, qp=ptr(self._qp), act=ptr(self._act),
                                mono=ptr(self._mono), c2=ptr(self._c2), sgn=ptr(self._sgn), work=ptr(self._work),
                                flags=ptr(self._flags))
-        # ---- per-step scratch ----
+
+    def _finish_state(self, keep_alive):
+        """per-step scratch, constants and the prefactor of t = 0 once (q, p, S, M) and (zi, probi) are in place"""
+        dev, n, d = self.device, self.ntraj, self.dim
+        self._ic_bufs = keep_alive                    # device operands of a sampling launch that may still be running
         self._gstep = lib.sc_step_grid(n, d)
         self._gcorr = lib.sc_correlate_grid(n, d)
         self._epart = torch.zeros(self._gstep, dtype=F64, device=dev)
