@@ -155,6 +155,11 @@ typedef struct sc_wm_consts {
      * rank): sc_wm_scratch_bytes(n, D, d') bytes of device memory, 0 / NULL when not needed.  Contents are scratch. */
     double *scratch;
     int64_t scratch_bytes;
+    /* [n + 1] int32 scratch, or NULL.  The register-resident kernel eliminates in a fixed pivot order; a trajectory
+     * whose pivot falls more than a factor 16 below what partial pivoting would have picked is marked flags[i] = 1
+     * (flags[n] counts them) and recomputed with full partial pivoting by the LDS kernel in the same call.  NULL: no
+     * such re-run (the fixed-order result is used as it is). */
+    int32_t *flags;
 } sc_wm_consts;
 
 /* sGDML force field, reference semiclassical/gdml_predictor.py:57-85 (constructor) and :96-250 (forward).
@@ -256,7 +261,8 @@ int sc_reduce_slot_at(const double *corr_partials, int32_t n_corr, double *slots
  *   cq_out/kq_out complex [n] may be NULL; partials[sc_wm_grid()][4] as in sc_hk_correlate.
  * Three kernels behind it: a register-resident one (D <= 16, e <= 16 at the instantiated shapes), one with every matrix of
  * the trajectory in LDS, and the same with the matrices in wc->scratch for shapes beyond the LDS (no size limit other
- * than memory: sc_wm_scratch_bytes says how much scratch the call needs, 0 if none, -1 for invalid shapes). */
+ * than memory: sc_wm_scratch_bytes says how much scratch the call needs, 0 if none, -1 for invalid shapes).
+ * sc_wm_grid: rows of `partials` the caller provides and sums (the kernels' own slots + those of the pivoted re-run). */
 int sc_wm_grid(int64_t n, int32_t dim);
 int64_t sc_wm_scratch_bytes(int64_t n, int32_t dim, int32_t dprime);
 int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi, const double *probi,

@@ -45,6 +45,112 @@ __device__ __forceinline__ double bc(double v) {
     return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, true);
 }
 
+// ---- broadcast FUSED into the multiply-add (round 3) ----
+// v_fmac_f64 is the one 64-bit VALU operation that takes a DPP operand on gfx90a+/gfx950 (DP-ALU DPP, row_newbcast only):
+//     acc += b[lane K of this lane's 16-lane row] * a          in ONE instruction, at the rate of a plain v_fmac_f64
+// (tools/micro/dpp_fmac.hip, profiles/r3_dpp_fmac.txt: 1.7x the rate of v_mov_b64_dpp + v_fmac_f64, identical results).
+// hipcc never forms it (its DPP combiner runs while the multiply-add is still the three-address VOP3 v_fma_f64), hence
+// inline assembly.  `volatile`: the statements keep their source order -- the register pressure of a product loop is the
+// one written down, not what a list scheduler makes of several thousand independent multiply-adds.
+// HAZARD the compiler cannot see: a VGPR written by a VALU instruction must not be read as the DPP operand by one of the
+// next two instructions.  The DPP operands of every loop below are arrays completed in an earlier phase; `dpp_guard()`
+// (s_nop 1) separates a phase from the code that produced its operands, and tests/test_host.py::test_dpp_hazards scans
+// the disassembly of the built library for any DPP read closer than that to a write of the same register.
+__device__ __forceinline__ void dpp_guard() { asm volatile("s_nop 1"); }
+
+template <int K>
+__device__ __forceinline__ void fmac_bc(double &acc, const double &b, const double &a) {      // acc += b[K] * a
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(a), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void fnmac_bc(double &acc, const double &b, const double &a) {     // acc -= b[K] * a
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(a), "n"(K));
+}
+// c += w * x[K] and c -= w * x[K] (complex; x is taken from lane K, w is this lane's).  c and x must be DIFFERENT
+// registers (an in-place update would read x as DPP operand right behind its own write: cfnma_inplace below).
+template <int K>
+__device__ __forceinline__ void cfma_bc(cplx &c, const cplx &x, const cplx &w) {
+    asm volatile("v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                 : "+v"(c.x), "+v"(c.y) : "v"(x.x), "v"(x.y), "v"(w.x), "v"(w.y), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void cfnma_bc(cplx &c, const cplx &x, const cplx &w) {
+    asm volatile("v_fmac_f64_dpp %0, %2, -%4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %3, -%4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %3, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                 : "+v"(c.x), "+v"(c.y) : "v"(x.x), "v"(x.y), "v"(w.x), "v"(w.y), "n"(K));
+}
+
+// IN-PLACE elimination update  c_j -= w * c_j[K]  of N array elements (the pivot lane K's own w must be zero, so that
+// what the other lanes read from it does not change under the update).  The four multiply-adds of every element are
+// issued phase by phase over the group -- all "x -= X.x w.x", all "y -= X.y w.x", all "x += X.y w.y", all "y -= X.x w.y"
+// -- so that a register is read as DPP operand no earlier than N - 1 instructions after it was written: with N >= 3 the
+// two wait states the hardware wants lie in between without a single s_nop.  Groups of one and two carry the s_nop.
+#define SC_IP_A(c) "v_fmac_f64_dpp %[" #c "x], %[" #c "x], -%[wx] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+#define SC_IP_B(c) "v_fmac_f64_dpp %[" #c "y], %[" #c "y], -%[wx] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+#define SC_IP_C(c) "v_fmac_f64_dpp %[" #c "x], %[" #c "y], %[wy] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+#define SC_IP_D(c) "v_fmac_f64_dpp %[" #c "y], %[" #c "x], -%[wy] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+#define SC_IP_IO(c, v) [c##x] "+v"(v.x), [c##y] "+v"(v.y)
+#define SC_IP_IN [wx] "v"(w.x), [wy] "v"(w.y), [k] "n"(K)
+template <int K>
+__device__ __forceinline__ void cfnma_inplace(cplx &a, const cplx &w) {
+    asm volatile(SC_IP_A(a) SC_IP_B(a) "s_nop 1\n\t" SC_IP_C(a) "s_nop 1\n\t" SC_IP_D(a) : SC_IP_IO(a, a) : SC_IP_IN);
+}
+template <int K>
+__device__ __forceinline__ void cfnma_inplace(cplx &a, cplx &b, const cplx &w) {
+    asm volatile(SC_IP_A(a) SC_IP_A(b) SC_IP_B(a) SC_IP_B(b) "s_nop 0\n\t" SC_IP_C(a) SC_IP_C(b) "s_nop 0\n\t" SC_IP_D(a) SC_IP_D(b)
+                 : SC_IP_IO(a, a), SC_IP_IO(b, b) : SC_IP_IN);
+}
+template <int K>
+__device__ __forceinline__ void cfnma_inplace(cplx &a, cplx &b, cplx &c, const cplx &w) {
+    asm volatile(SC_IP_A(a) SC_IP_A(b) SC_IP_A(c) SC_IP_B(a) SC_IP_B(b) SC_IP_B(c)
+                 SC_IP_C(a) SC_IP_C(b) SC_IP_C(c) SC_IP_D(a) SC_IP_D(b) SC_IP_D(c)
+                 : SC_IP_IO(a, a), SC_IP_IO(b, b), SC_IP_IO(c, c) : SC_IP_IN);
+}
+template <int K>
+__device__ __forceinline__ void cfnma_inplace(cplx &a, cplx &b, cplx &c, cplx &d, const cplx &w) {
+    asm volatile(SC_IP_A(a) SC_IP_A(b) SC_IP_A(c) SC_IP_A(d) SC_IP_B(a) SC_IP_B(b) SC_IP_B(c) SC_IP_B(d)
+                 SC_IP_C(a) SC_IP_C(b) SC_IP_C(c) SC_IP_C(d) SC_IP_D(a) SC_IP_D(b) SC_IP_D(c) SC_IP_D(d)
+                 : SC_IP_IO(a, a), SC_IP_IO(b, b), SC_IP_IO(c, c), SC_IP_IO(d, d) : SC_IP_IN);
+}
+template <int K>
+__device__ __forceinline__ void cfnma_inplace(cplx &a, cplx &b, cplx &c, cplx &d, cplx &e, const cplx &w) {
+    asm volatile(SC_IP_A(a) SC_IP_A(b) SC_IP_A(c) SC_IP_A(d) SC_IP_A(e) SC_IP_B(a) SC_IP_B(b) SC_IP_B(c) SC_IP_B(d) SC_IP_B(e)
+                 SC_IP_C(a) SC_IP_C(b) SC_IP_C(c) SC_IP_C(d) SC_IP_C(e) SC_IP_D(a) SC_IP_D(b) SC_IP_D(c) SC_IP_D(d) SC_IP_D(e)
+                 : SC_IP_IO(a, a), SC_IP_IO(b, b), SC_IP_IO(c, c), SC_IP_IO(d, d), SC_IP_IO(e, e) : SC_IP_IN);
+}
+// elements I0 .. I1-1 of `v`, in groups of three (the last group takes what is left: 1 .. 5)
+template <int K, int I0, int I1, int N>
+__device__ __forceinline__ void cfnma_inplace_range(cplx (&v)[N], const cplx &w) {
+    constexpr int n = I1 - I0;
+    if constexpr (n == 1) cfnma_inplace<K>(v[I0], w);
+    else if constexpr (n == 2) cfnma_inplace<K>(v[I0], v[I0 + 1], w);
+    else if constexpr (n == 3) cfnma_inplace<K>(v[I0], v[I0 + 1], v[I0 + 2], w);
+    else if constexpr (n == 4) cfnma_inplace<K>(v[I0], v[I0 + 1], v[I0 + 2], v[I0 + 3], w);
+    else if constexpr (n == 5) cfnma_inplace<K>(v[I0], v[I0 + 1], v[I0 + 2], v[I0 + 3], v[I0 + 4], w);
+    else if constexpr (n > 5) {
+        cfnma_inplace<K>(v[I0], v[I0 + 1], v[I0 + 2], w);
+        cfnma_inplace_range<K, I0 + 3, I1>(v, w);
+    }
+}
+// value of lane K of the row (32-bit)
+template <int K>
+__device__ __forceinline__ int bc_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xF, 0xF, true);
+}
+// 1/z with a hardware reciprocal refined by two Newton steps (full fp64 accuracy for normal |z|^2)
+__device__ __forceinline__ cplx c_inv_newton(cplx z) {
+    const double x = c_abs2(z);
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return c_make(z.x * r, -z.y * r);
+}
+
 // sum over the 16 lanes of the row, result in every lane of the row; fixed order
 __device__ __forceinline__ double row_sum(double v) {
     v += dpp_mov_f64<0x128>(v);

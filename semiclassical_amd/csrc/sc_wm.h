@@ -15,6 +15,7 @@ struct WmArgs {
     double *scratch;    // general kernel, large D: per-workgroup matrix storage in global memory (NULL: LDS)
     size_t scratch_stride;   // bytes per workgroup
     int npartials;      // slots of `partials` the caller sums (sc_wm_grid); the kernels fill all of them
+    const int32_t *only_flagged;   // general kernel: NULL, or [n + 1] flags -- process trajectory i only if only_flagged[i] != 0
 };
 
 // branch tracker of sqrt(z(t)), reference propagators.py:1006-1052; returns the sign to use now

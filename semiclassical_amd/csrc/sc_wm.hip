@@ -133,7 +133,11 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     const double ihb = 1.0 / SC_HBAR;
     double acc[4] = {0, 0, 0, 0};
 
-    for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x) {
+    // re-run of the trajectories the register kernel flagged (fixed pivot order too weak): nothing to do in the common case
+    const int32_t *only = A.only_flagged;
+    const bool idle = only && only[A.st.n] == 0;
+    for (int64_t tr = blockIdx.x; tr < A.st.n && !idle; tr += gridDim.x) {
+        if (only && !only[tr]) continue;
         const double *qp = A.st.qp + tr * 2 * D, *zi = A.zi + tr * 2 * D;
         const double *M = A.st.mono + tr * 4 * (int64_t)DD;
         __syncthreads();
@@ -547,9 +551,13 @@ extern "C" int sc_wm_grid_sum(const double *qp, const double *coef, const double
     return sc_check_launch("sc_wm_grid_sum");
 }
 
+// partial-sum slots: the first wm_main_grid(n) belong to the kernel that processes all trajectories, the last
+// WM_RERUN_GRID to the pivoted re-run of the trajectories the register kernel flagged
+static const int WM_RERUN_GRID = 256;
+static int wm_main_grid(int64_t n) { return (int)(n < 2048 ? (n > 0 ? n : 1) : 2048); }
 extern "C" int sc_wm_grid(int64_t n, int32_t dim) {
     (void)dim;
-    return (int)(n < 2048 ? (n > 0 ? n : 1) : 2048);
+    return wm_main_grid(n) + WM_RERUN_GRID;
 }
 
 // workgroups of the global-scratch variant: bounded so that the scratch stays within a few hundred MB
@@ -573,17 +581,41 @@ extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const
     if (int rq = sc_require_rowmajor(st, "sc_wm_correlate")) return rq;
     if (wc->dprime < 1 || wc->dprime > st->dim) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: d' outside 1..D");
     if (st->n <= 0) return SC_OK;
-    const int D = st->dim, dp = wc->dprime, grid = sc_wm_grid(st->n, D);
+    const int D = st->dim, dp = wc->dprime, grid = wm_main_grid(st->n), slots = sc_wm_grid(st->n, D);
     WmArgs a;
     a.st = *st; a.wc = *wc; a.zi = zi; a.probi = probi; a.mc_norm = mc_norm; a.track = track; a.has_nac = has_nac;
     a.stage_consts = 0; a.cq_out = cq_out; a.kq_out = kq_out; a.partials = partials;
-    a.scratch = nullptr; a.scratch_stride = 0; a.npartials = grid;
+    a.scratch = nullptr; a.scratch_stride = 0; a.npartials = slots; a.only_flagged = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (wm_has_small_kernel(D, dp)) {
-        const int rc = sc_wm_launch_small(a, grid, s);
-        if (rc != 0) return rc < 0 ? rc : SC_OK;
-    }
     size_t lds = wm_lds_bytes(D, dp);
+    // the LDS kernel (every matrix of a trajectory in LDS, full partial pivoting): all trajectories, or only the flagged ones
+    auto launch_lds_kernel = [&](int nblocks) {
+        a.stage_consts = lds + wm_const_bytes(D, dp) <= 64 * 1024;   // keep >= 2 workgroups per CU
+        size_t bytes = lds + (a.stage_consts ? wm_const_bytes(D, dp) : 0);
+        if (hipFuncSetAttribute((const void *)wm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+            return sc_check_launch("sc_wm_correlate (LDS attribute)");
+        const int threads = D <= 16 ? 64 : 256;
+        hipLaunchKernelGGL(wm_kernel<false>, dim3(nblocks), dim3(threads), bytes, s, a);
+        return sc_check_launch("sc_wm_correlate");
+    };
+    if (wm_has_small_kernel(D, dp)) {
+        if (wc->flags && hipMemsetAsync(wc->flags + st->n, 0, sizeof(int32_t), s) != hipSuccess)
+            return sc_check_launch("sc_wm_correlate (flag counter)");
+        const int rc = sc_wm_launch_small(a, grid, s);
+        if (rc < 0) return rc;
+        if (rc != 0) {
+            // slots of the re-run: written by it (zeros from its idle workgroups), or cleared here when there is none
+            a.partials = partials + 4 * (size_t)grid;
+            a.npartials = WM_RERUN_GRID;
+            if (!wc->flags) {
+                if (hipMemsetAsync(a.partials, 0, 4 * sizeof(double) * WM_RERUN_GRID, s) != hipSuccess)
+                    return sc_check_launch("sc_wm_correlate (re-run slots)");
+                return SC_OK;
+            }
+            a.only_flagged = wc->flags;
+            return launch_lds_kernel(WM_RERUN_GRID);
+        }
+    }
     if (lds > 160 * 1024) {
         // the matrices of one trajectory do not fit LDS: run the same kernel on the caller's scratch block
         const int gs = wm_scratch_grid(st->n);
@@ -595,11 +627,5 @@ extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const
         hipLaunchKernelGGL(wm_kernel<true>, dim3(gs), dim3(256), 0, s, a);
         return sc_check_launch("sc_wm_correlate (global scratch)");
     }
-    a.stage_consts = lds + wm_const_bytes(D, dp) <= 64 * 1024;   // keep >= 2 workgroups per CU
-    if (a.stage_consts) lds += wm_const_bytes(D, dp);
-    if (hipFuncSetAttribute((const void *)wm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return sc_check_launch("sc_wm_correlate (LDS attribute)");
-    const int threads = D <= 16 ? 64 : 256;
-    hipLaunchKernelGGL(wm_kernel<false>, dim3(grid), dim3(threads), lds, s, a);
-    return sc_check_launch("sc_wm_correlate");
+    return launch_lds_kernel(grid);
 }

@@ -6,16 +6,23 @@
 //   * one trajectory per 16-lane DPP row, four trajectories per wavefront, sixteen per workgroup; lane r of a row holds
 //     ROW r of every matrix of its trajectory in registers (D, d' are template parameters: all loops are unrolled and
 //     every register index is static);
-//   * products C = A B (A, B both per trajectory) take row k of B from lane k with a 64-bit DPP row_newbcast (the lane
-//     is an immediate because k is a compile-time loop index); products with a constant matrix take the constant from
-//     scalar registers (constant address space => s_load) and cost no cross-lane traffic at all;
-//   * the two linear systems are solved by Gauss-Jordan elimination with TRUE partial pivoting where the pivot is a
-//     LANE, not a register: the pivot row is picked by an integer-key DPP maximum over the unused lanes and broadcast
-//     with ds_bpermute (the only data-dependent lane index in the kernel), so no register is ever indexed dynamically.
-//     Nothing is inverted explicitly: A'^T Wm^T = BQ'^T is solved for the D right-hand sides the later formulas need
-//     (57, 59), and M' rho = hat for the five vectors of the bilinear forms;
-//   * LDS holds only the per-lane rows of the constants (staged once per workgroup) and one small exchange buffer per
-//     trajectory for the two transpositions (columns of Mq', Mp'; rows of Wm);  there is no __syncthreads in the loop.
+//   * EVERY matrix product is a chain of v_fmac_f64_dpp row_newbcast (sc_row16.h: the 16-lane broadcast of the other
+//     factor's row fused into the multiply-add, one instruction per multiply-add, no cross-lane move, no LDS, no scalar
+//     operand traffic): C[r][j] += A[r][k] * B[k][j] takes B[k][j] from lane k, and products with a constant matrix take
+//     the constant's row k from lane k as well (the per-lane rows of the constants are staged in LDS once per workgroup
+//     and read where they are used);
+//   * the two linear systems are eliminated IN A FIXED PIVOT ORDER, so that the pivot row is a static lane and the
+//     elimination is made of the same fused instructions (round 2 searched the pivot among the lanes and fetched its row
+//     with ds_bpermute: 1100 LDS operations per four trajectories on the critical path).  W A' = BQ' (eqns 57, 59 need
+//     W = BQ' A'^-1) is solved by column operations on [A'; BQ'] with lane j holding row j of both -- forward elimination
+//     with normalised pivot rows, then back substitution -- which leaves row a of W in lane a, where the following
+//     products want it (no transposition).  M' rho = hat is solved for its five right-hand sides by row operations.
+//     A pivot is accepted if it is within a factor 16 of the largest candidate partial pivoting could have chosen
+//     (threshold pivoting; candidates are registers of the pivot lane resp. lanes of the pivot column); otherwise the
+//     trajectory is flagged (sc_wm_consts.flags) and recomputed by the fully pivoted LDS kernel wm_kernel<false> in the
+//     same stream -- the scheme of the HK fast path (sc_hk_step_sd.hip);
+//   * LDS holds the per-lane rows of the constants and one D x (e|1) transposition buffer per trajectory (columns of Mq',
+//     Mp'); there is no __syncthreads in the loop;  the kernel is compiled for two wavefronts per SIMD (256 registers).
 //
 // Restatement (see sc_wm.hip for the derivation): e = 2d', Mq' = [Mqq U, Mqp U], Mp' = [Mpq U, Mpp U],
 //   A' = Cst' + Mq'^T Gt Mq' + i/hbar (2G - H),  G = Mp'^T Mq',  H[i][j] = i < d' ? G[i][j] : G[j][i],
@@ -26,35 +33,40 @@
 
 namespace {
 
-// bytes of LDS: constants (doubles) + per-group exchange buffers (complex)
+// bytes of LDS: per-lane rows of the constants (doubles) + per-trajectory transposition buffers (doubles)
 template <int D, int DP>
 struct WmSmallLayout {
-    static constexpr int E = 2 * DP, EP = E + 1;
+    static constexpr int E = 2 * DP, EP = E | 1;
     static constexpr int n_const = 5 * 16 * D        // rows of Gt, G0, Cqq, S, iGi0, zero padded to 16 lanes
                                    + 16 * D          // UT[i][a] = U[a][i], zero for i >= d'
-                                   + 2 * 16 * E      // CstT[i][j] = Cst[j][i] (complex), zero for i >= e
+                                   + 3 * 16 * DP     // rows of U, Re Bq'[:, :d'] = Gamma_i U, Im Bq'[:, d':] = -U / hbar
+                                   + 2 * 16 * E      // rows of Cst' / s (complex), zero for r >= e
                                    + 8 * 16;         // q0, p0, n1, s_n1, w_n1, crow = Cqq n1, 2 spare
-    static constexpr int H = (D + 1) / 2;            // rows per half of the Wm exchange
-    static constexpr int xh = H * EP;                // complex: transposition buffer (D x EP reals fit as well)
-    static constexpr int xq = (E > D ? E : D) * D;   // complex: BQ'^T (e x D), later the rows of Gti (D x D)
-    static constexpr int xbuf = xh + xq;             // complex values per trajectory
-    static constexpr size_t bytes = (size_t)n_const * 8 + (size_t)16 * xbuf * 16 + 16 * 4 * 8;
+    static constexpr int PB = 2 * E + 2;             // doubles per lane of the parked BQ' row (pitch: 16-byte aligned, odd in 16-byte units)
+    static constexpr int xt = D * EP + 16;           // transposition buffer (+16: lanes beyond the matrix read, never use)
+    static constexpr int xbuf = (xt > 16 * PB ? xt : 16 * PB) + (xt > 16 * PB ? xt & 1 : 0);   // doubles per trajectory
+    static constexpr size_t bytes = (size_t)n_const * 8 + (size_t)16 * xbuf * 8 + 16 * 4 * 8;
 };
 
 #ifndef SC_WM_SMALL_OCC
-// waves per SIMD the kernel is compiled for (register budget 512 / OCC).  Measured on MI355X, methylium (12, 6),
-// n = 1e5: 1 -> 1.37 ms (the allocator parks idle rows in AGPRs), 2 -> 2.3 .. 2.9 ms (the same rows go to scratch).
-#define SC_WM_SMALL_OCC 1
+// waves per SIMD the kernel is compiled for (register budget 512 / OCC)
+#define SC_WM_SMALL_OCC 2
 #endif
+#ifndef SC_WM_FORCE_WEAK
+#define SC_WM_FORCE_WEAK 0     // 1: variant library that flags EVERY trajectory (tests of the pivoted fallback)
+#endif
+
+// |pivot|^2 more than 2^8 below the largest candidate: hand the trajectory to the pivoted kernel
+__device__ __forceinline__ bool weak_keys(int key_pivot, int key_max) { return key_max - key_pivot > (8 << 20); }
 
 template <int D, int DP>
 __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A) {
     typedef WmSmallLayout<D, DP> L;
     constexpr int E = L::E, EP = L::EP, DD = D * D;
     extern __shared__ double2 smem2[];
-    const int tid = threadIdx.x, r = tid & 15, grp = tid >> 4, rowbase = tid & 48;
+    const int tid = threadIdx.x, r = tid & 15, grp = tid >> 4;
     const sc_wm_consts &W = A.wc;
-    const double ihb = 1.0 / SC_HBAR;
+    const double ihb = 1.0 / SC_HBAR, sA = W.inv_scale_a;
 
     double *ls = (double *)smem2;
     double *sGt = ls;   ls += 16 * D;
@@ -63,10 +75,13 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     double *sS = ls;    ls += 16 * D;
     double *siG = ls;   ls += 16 * D;
     double *sUT = ls;   ls += 16 * D;
-    double *sCstT = ls; ls += 2 * 16 * E;
+    double *sU = ls;    ls += 16 * DP;
+    double *sBr = ls;   ls += 16 * DP;
+    double *sBi = ls;   ls += 16 * DP;
+    double *sCst = ls;  ls += 2 * 16 * E;
     double *cvec = ls;  ls += 8 * 16;            // [q0 | p0 | n1 | s_n1 | w_n1 | crow | - | -][16]
-    cplx *xall = (cplx *)ls;
-    double *red = (double *)(xall + 16 * L::xbuf);
+    double *xall = ls;  ls += 16 * L::xbuf;
+    double *red = ls;
 
     // ---- stage the per-lane rows of the constants (once per workgroup) ----
     for (int e = tid; e < 16 * D; e += 256) {
@@ -79,10 +94,17 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
         siG[e] = in ? W.iGi0[i * D + b] : 0.0;
         sUT[e] = i < DP ? W.U[b * DP + i] : 0.0;
     }
+    for (int e = tid; e < 16 * DP; e += 256) {
+        const int i = e / DP, k = e - i * DP;
+        const bool in = i < D;
+        sU[e] = in ? W.U[i * DP + k] : 0.0;
+        sBr[e] = in ? W.Bq[2 * (i * E + k)] : 0.0;                   // Re Bq'[i][k]      = (Gamma_i U)[i][k]
+        sBi[e] = in ? W.Bq[2 * (i * E + DP + k) + 1] : 0.0;          // Im Bq'[i][d' + k] = -U[i][k] / hbar
+    }
     for (int e = tid; e < 16 * E; e += 256) {
         const int i = e / E, j = e - i * E;
-        sCstT[2 * e] = i < E ? W.Cst[2 * (j * E + i)] : 0.0;
-        sCstT[2 * e + 1] = i < E ? W.Cst[2 * (j * E + i) + 1] : 0.0;
+        sCst[2 * e] = i < E ? W.Cst[2 * (i * E + j)] * sA : 0.0;
+        sCst[2 * e + 1] = i < E ? W.Cst[2 * (i * E + j) + 1] * sA : 0.0;
     }
     if (tid < 16) {
         const bool in = tid < D, nac = in && A.has_nac;
@@ -97,69 +119,67 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     }
     __syncthreads();
 
-    kptr kU = (kptr)W.U, kGt = (kptr)W.Gt, kiG = (kptr)W.iGi0, kBq = (kptr)W.Bq;
-    const double q0r = cvec[r], p0r = cvec[16 + r], n1r = cvec[32 + r], wn1r = cvec[64 + r], crowr = cvec[80 + r];
-    cplx *xc = xall + grp * L::xbuf;        // exchange buffers of this trajectory: transpositions ...
-    double *xr = (double *)xc;
-    cplx *xq = xc + L::xh;                  // ... and group-uniform operands (BQ'^T, then the rows of Gti)
-
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double *xr = xall + grp * L::xbuf;          // transposition buffer of this trajectory
+    if (r < 4) red[grp * 4 + r] = 0.0;          // running sums of this 16-lane row's trajectories (lane 0 adds, fixed order)
     const int64_t n = A.st.n, stride = (int64_t)gridDim.x * 16;
     for (int64_t t0 = (int64_t)blockIdx.x * 16; t0 < n; t0 += stride) {
         const bool active = t0 + grp < n;
         const int64_t tr = active ? t0 + grp : n - 1;      // idle rows redo the last trajectory and discard it
         const double *qp = A.st.qp + tr * 2 * D, *zi = A.zi + tr * 2 * D;
         const double *M = A.st.mono + tr * 4 * (int64_t)DD;
-        // the scalar loads of the constants are redone per trajectory next to their use: hoisted out of the loop they
-        // would occupy (and spill) several hundred scalar registers
-        asm volatile("" : "+s"(kU), "+s"(kGt), "+s"(kiG), "+s"(kBq));
-        // the same for the per-lane rows of the constants in LDS: read where they are used, never kept across phases
+        // the per-lane rows of the constants are read from LDS where they are used, never kept across phases
         int lofs = 0;
         asm volatile("" : "+v"(lofs));
-        const double *cGt = sGt + lofs, *cG0 = sG0 + lofs, *cCqq = sCqq + lofs, *cS = sS + lofs, *ciG = siG + lofs;
-        const double *cUT = sUT + lofs, *cCstT = sCstT + lofs;
+        const double *cGt = sGt + lofs + r * D, *cG0 = sG0 + lofs + r * D, *cCqq = sCqq + lofs + r * D, *cS = sS + lofs + r * D;
+        const double *ciG = siG + lofs + r * D, *cUT = sUT + lofs + r * D, *cU = sU + lofs + r * DP, *cBr = sBr + lofs + r * DP;
+        const double *cBi = sBi + lofs + r * DP;
+        const cplx *cCst = (const cplx *)(sCst + lofs) + r * E;
+        const double *cv = cvec + lofs;
 
         // ---- rows of the monodromy blocks; Mq' = [Mqq U, Mqp U], Mp' = [Mpq U, Mpp U] (row r) ----
         double Mq[E], Mp[E];
-        double qv = 0.0, pv = 0.0, dq = 0.0, dpv = 0.0;
-        WM_BLOCK {
-            double mqq[D], mqp[D], mpq[D], mpp[D];
+        double qv = 0.0, pv = 0.0, dq = 0.0, dpv = 0.0, dQ = 0.0;
+        {
+            double m0[D], m1[D], m2[D], m3[D];
 #pragma unroll
-            for (int b = 0; b < D; ++b) { mqq[b] = 0.0; mqp[b] = 0.0; mpq[b] = 0.0; mpp[b] = 0.0; }
+            for (int b = 0; b < D; ++b) { m0[b] = 0.0; m1[b] = 0.0; m2[b] = 0.0; m3[b] = 0.0; }
             if (r < D) {
 #pragma unroll
                 for (int b = 0; b < D; ++b) {
-                    mqq[b] = M[r * D + b]; mqp[b] = M[DD + r * D + b];
-                    mpq[b] = M[2 * DD + r * D + b]; mpp[b] = M[3 * DD + r * D + b];
+                    m0[b] = M[r * D + b]; m1[b] = M[DD + r * D + b];
+                    m2[b] = M[2 * DD + r * D + b]; m3[b] = M[3 * DD + r * D + b];
                 }
                 qv = qp[r]; pv = qp[D + r];
-                dq = q0r - zi[r]; dpv = p0r - zi[D + r];
+                dq = cv[r] - zi[r]; dpv = cv[16 + r] - zi[D + r];
+                dQ = cv[r] - qv;
             }
+            double ur[DP];
+#pragma unroll
+            for (int j = 0; j < DP; ++j) ur[j] = cU[j];
 #pragma unroll
             for (int j = 0; j < E; ++j) { Mq[j] = 0.0; Mp[j] = 0.0; }
-            // one ROW of U (contiguous scalar loads) per block: the scalar registers hold d' constants at a time
-            sfor_bb<0, D>([&](auto bcn) {
+            dpp_guard();
+            sfor<0, D>([&](auto bcn) {
                 constexpr int b = decltype(bcn)::value;
 #pragma unroll
                 for (int j = 0; j < DP; ++j) {
-                    const double u = kU[b * DP + j];
-                    Mq[j] = fma(mqq[b], u, Mq[j]); Mq[DP + j] = fma(mqp[b], u, Mq[DP + j]);
-                    Mp[j] = fma(mpq[b], u, Mp[j]); Mp[DP + j] = fma(mpp[b], u, Mp[DP + j]);
+                    fmac_bc<b>(Mq[j], ur[j], m0[b]); fmac_bc<b>(Mq[DP + j], ur[j], m1[b]);
+                    fmac_bc<b>(Mp[j], ur[j], m2[b]); fmac_bc<b>(Mp[DP + j], ur[j], m3[b]);
                 }
             });
         }
-        const double dQ = r < D ? q0r - qv : 0.0;
 
-        // ---- columns of Mq', Mp' (lane i < e holds column i) through the exchange buffer; TqT = (Gt Mq')^T ----
-        double MqT[D], MpT[D], TqT[D];
-        WM_BLOCK {
+        // ---- columns of Mq', Mp' (lane i < e holds column i) through the transposition buffer ----
+        double MqT[D], MpT[D];
+        {
+            const int rc = r < E ? r : E - 1;
             if (r < D) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) xr[r * EP + j] = Mq[j];
             }
             wave_lds_fence();
 #pragma unroll
-            for (int a = 0; a < D; ++a) MqT[a] = r < E ? xr[a * EP + r] : 0.0;
+            for (int a = 0; a < D; ++a) { const double x = xr[a * EP + rc]; MqT[a] = r < E ? x : 0.0; }
             wave_lds_fence();
             if (r < D) {
 #pragma unroll
@@ -167,155 +187,155 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             }
             wave_lds_fence();
 #pragma unroll
-            for (int a = 0; a < D; ++a) MpT[a] = r < E ? xr[a * EP + r] : 0.0;
+            for (int a = 0; a < D; ++a) { const double x = xr[a * EP + rc]; MpT[a] = r < E ? x : 0.0; }
             wave_lds_fence();
         }
-        sfor_bb<0, D>([&](auto ac) {      // in-lane with the constant (symmetric) Gt, one row of it per block
-            constexpr int a = decltype(ac)::value;
-            double s = 0.0;
+        // ---- Tq = Gt Mq' (row r) ----
+        double Tq[E];
+        {
+            double gt[D];
 #pragma unroll
-            for (int b = 0; b < D; ++b) s = fma(kGt[a * D + b], MqT[b], s);
-            TqT[a] = s;
-        });
-
-        // ---- GT[i][j] = G[j][i] first (the last use of Mp' rows and Mq' columns), then G = Mp'^T Mq' (row i) and
-        //      ST[i][j] = (Mq'^T Gt Mq')[j][i] ----
-        double G[E], ST[E], GT[E];
+            for (int b = 0; b < D; ++b) gt[b] = cGt[b];
 #pragma unroll
-        for (int j = 0; j < E; ++j) GT[j] = 0.0;
-        sfor_bb<0, D>([&](auto ac) {
-            constexpr int a = decltype(ac)::value;
+            for (int j = 0; j < E; ++j) Tq[j] = 0.0;
+            dpp_guard();
+            sfor<0, D>([&](auto bcn) {
+                constexpr int b = decltype(bcn)::value;
 #pragma unroll
-            for (int j = 0; j < E; ++j) GT[j] = fma(MqT[a], bc<a>(Mp[j]), GT[j]);
-        });
-#pragma unroll
-        for (int j = 0; j < E; ++j) { G[j] = 0.0; ST[j] = 0.0; }
-        sfor_bb<0, D>([&](auto ac) {
-            constexpr int a = decltype(ac)::value;
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                const double x = bc<a>(Mq[j]);
-                G[j] = fma(MpT[a], x, G[j]);
-                ST[j] = fma(TqT[a], x, ST[j]);
-            }
-        });
-
-        // ---- row i of (A'/s)^T and of the right-hand sides BQ'^T ----
-        cplx At[E], Rh[D];
-        WM_BLOCK {
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                const double cre = cCstT[2 * (r * E + j)], cim = cCstT[2 * (r * E + j) + 1];
-                const double im = j < DP ? GT[j] : 2.0 * GT[j] - G[j];
-                At[j] = c_make((cre + ST[j]) * W.inv_scale_a, (cim + ihb * im) * W.inv_scale_a);
-            }
-#pragma unroll
-            for (int a = 0; a < D; ++a) Rh[a] = c_make(TqT[a], ihb * MpT[a]);
-            // BQ'^T also goes to LDS: eqn (57) reads it back as group-uniform operands after the elimination
-            if (r < E) {
-#pragma unroll
-                for (int a = 0; a < D; ++a) xq[r * D + a] = Rh[a];
-            }
+                for (int j = 0; j < E; ++j) fmac_bc<b>(Tq[j], Mq[j], gt[b]);
+            });
         }
 
-        int myk, src;
-        cplx detA;
-        gauss_jordan_rows<E, D>(At, Rh, r >= E, r, rowbase, myk, src, detA);
-
-        // ---- Wm = BQ' A'^-1: the pivot lane of step k holds Wm[:, k] (scaled by s); write it as column k, read row r ----
-        cplx Wm[E];
-        sfor_bb<0, 2>([&](auto hc) {               // two halves of the rows: the exchange buffer holds (D+1)/2 of them
-            constexpr int h0 = decltype(hc)::value ? L::H : 0, h1 = decltype(hc)::value ? D : L::H;
-            if (r < E) {
+        // ---- row j = r of A'/s:  Re = Cst + Mq'^T Tq,  Im = Cst + i/hbar (2G - H):  H[j][i] = j < d' ? G[j][i] : G[i][j],
+        //      G[j][i] = sum_a Mp'[a][j] Mq'[a][i] -- accumulated straight into the matrix, coefficients folded per lane ----
+        cplx rowA[E];
+        {
 #pragma unroll
-                for (int a = h0; a < h1; ++a) xc[(a - h0) * EP + myk] = c_scale(Rh[a], W.inv_scale_a);
-            }
-            wave_lds_fence();
-            if (r >= h0 && r < h1) {
+            for (int i = 0; i < E; ++i) rowA[i] = cCst[i];
+            const double sel = r < DP ? 0.0 : 1.0;
+            const double fa = (1.0 + sel) * ihb * sA, fb = -sel * ihb * sA;
+            double cs[D], ca[D], cb[D];
 #pragma unroll
-                for (int k = 0; k < E; ++k) Wm[k] = xc[(r - h0) * EP + k];
-            }
-            wave_lds_fence();
-        });
-        if (r >= D) {
+            for (int a = 0; a < D; ++a) { cs[a] = MqT[a] * sA; ca[a] = MpT[a] * fa; cb[a] = MqT[a] * fb; }
+            dpp_guard();
+            sfor<0, D>([&](auto ac) {
+                constexpr int a = decltype(ac)::value;
 #pragma unroll
-            for (int k = 0; k < E; ++k) Wm[k] = c_make(0.0, 0.0);
+                for (int i = 0; i < E; ++i) {
+                    fmac_bc<a>(rowA[i].x, Tq[i], cs[a]);
+                    fmac_bc<a>(rowA[i].y, Mq[i], ca[a]);
+                    fmac_bc<a>(rowA[i].y, Mp[i], cb[a]);
+                }
+            });
         }
-
-        // ---- Gt~ = Gt - Wm BQ'^T (57) ----
-        cplx Gtl[D], Gti[D];
+        // BQ' (row r) = Tq + i/hbar Mp': the elimination works on it in place; a copy for eqn (57) waits in LDS
+        cplx rowB[E];
+        cplx *park = (cplx *)(xr + r * L::PB);
 #pragma unroll
-        for (int b = 0; b < D; ++b) Gtl[b] = c_make(cGt[r * D + b], 0.0);
-        sfor_bb<0, E>([&](auto kc) {
+        for (int k = 0; k < E; ++k) { rowB[k] = c_make(Tq[k], ihb * Mp[k]); park[k] = rowB[k]; }
+
+        // ---- W (A'/s) = BQ' by column operations in the fixed pivot order 0 .. e-1 (see the header) ----
+        cplx detA = c_make(1.0, 0.0);
+        int weak = SC_WM_FORCE_WEAK;
+        dpp_guard();
+        sfor<0, E>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-#pragma unroll
-            for (int b = 0; b < D; ++b) Gtl[b] = c_fnma(Wm[k], xq[k * D + b], Gtl[b]);
+            // candidates of partial pivoting: entries k .. e-1 of the pivot lane's row
+            int key_max = 0;
+            sfor<k + 1, E>([&](auto ic) { key_max = max(key_max, __double2hiint(c_abs2(rowA[decltype(ic)::value]))); });
+            const double mag = c_abs2(rowA[k]);
+            if (r == k && (weak_keys(__double2hiint(mag), key_max) || mag == 0.0)) weak = 1;
+            const cplx piv = c_make(bc<k>(rowA[k].x), bc<k>(rowA[k].y));
+            detA = c_mul(detA, piv);
+            const cplx inv = c_inv_newton(piv);
+            const cplx tB = c_mul(rowB[k], inv);
+            const cplx tAf = c_mul(rowA[k], inv);
+            rowA[k] = tAf; rowB[k] = tB;
+            // the pivot lane's own entries below the diagonal are never read again: its multiplier is zeroed so that
+            // the in-place update below does not change what the other lanes read from it
+            const cplx tA = c_make(r == k ? 0.0 : tAf.x, r == k ? 0.0 : tAf.y);
+            dpp_guard();
+            sfor<k + 1, E>([&](auto ic) { cfnma_bc<k>(rowB[decltype(ic)::value], rowA[decltype(ic)::value], tB); });
+            cfnma_inplace_range<k, k + 1, E>(rowA, tA);
         });
-        // ---- Gti = Wm Bq'^T (59);  Bq' = [Gamma_i U | -i/hbar U]: real in its first d' columns, imaginary in the last d'
-        sfor_bb<0, D>([&](auto bcn) {
-            constexpr int b = decltype(bcn)::value;
-            cplx s = c_make(0.0, 0.0);
-#pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const double br = kBq[2 * (b * E + k)], bi = kBq[2 * (b * E + DP + k) + 1];
-                s.x = fma(Wm[k].x, br, s.x); s.y = fma(Wm[k].y, br, s.y);
-                s.x = fma(-Wm[DP + k].y, bi, s.x); s.y = fma(Wm[DP + k].x, bi, s.y);
-            }
-            Gti[b] = s;
+        sfor<1, E>([&](auto kc) {                      // back substitution, column k of the unit upper triangle
+            constexpr int k = E - decltype(kc)::value;
+            sfor<0, k>([&](auto ic) { cfnma_bc<k>(rowB[decltype(ic)::value], rowA[decltype(ic)::value], rowB[k]); });
         });
+
+        // ---- Wm = BQ' A'^-1 (row r);  Gt~ = Gt - Wm BQ'^T (57) ----
+        cplx Gtl[D], Gti[D];
+        {
+            cplx Wm[E], BQ[E];
+#pragma unroll
+            for (int k = 0; k < E; ++k) { Wm[k] = c_scale(rowB[k], sA); BQ[k] = park[k]; }
+#pragma unroll
+            for (int b = 0; b < D; ++b) Gtl[b] = c_make(cGt[b], 0.0);
+            dpp_guard();
+            sfor<0, D>([&](auto bcn) {
+                constexpr int b = decltype(bcn)::value;
+#pragma unroll
+                for (int k = 0; k < E; ++k) cfnma_bc<b>(Gtl[b], BQ[k], Wm[k]);
+            });
+            // ---- Gti = Wm Bq'^T (59);  Bq' = [Gamma_i U | -i/hbar U]: real in its first d' columns, imaginary in the last d'
+            double br[DP], bi[DP];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) { br[k] = cBr[k]; bi[k] = cBi[k]; }
+#pragma unroll
+            for (int b = 0; b < D; ++b) Gti[b] = c_make(0.0, 0.0);
+            dpp_guard();
+            sfor<0, D>([&](auto bcn) {
+                constexpr int b = decltype(bcn)::value;
+#pragma unroll
+                for (int k = 0; k < DP; ++k) {
+                    fmac_bc<b>(Gti[b].x, br[k], Wm[k].x); fmac_bc<b>(Gti[b].y, br[k], Wm[k].y);
+                    fnmac_bc<b>(Gti[b].x, bi[k], Wm[DP + k].y); fmac_bc<b>(Gti[b].y, bi[k], Wm[DP + k].x);
+                }
+            });
+        }
 
         // ---- per-trajectory vectors: g = iGi0 (p0 - p_i), s_dq = S dq, w_dQ = G0 dQ, cdq = Cqq dq, g0g = G0 g ----
         double gv = 0.0, sdq = 0.0, wdQ = 0.0, cdq = 0.0, g0g = 0.0;
+        const double p0r = cv[16 + r], n1r = cv[32 + r], sn1r = cv[48 + r], wn1r = cv[64 + r], crowr = cv[80 + r];
         cplx y = c_make(r < D ? pv - p0r : 0.0, 0.0), u1 = c_make(0.0, 0.0), u2 = c_make(0.0, 0.0);
-        WM_BLOCK {
-            sfor<0, D>([&](auto bcn) {
-                constexpr int b = decltype(bcn)::value;
-                const double xdp = bc<b>(dpv), xdq = bc<b>(dq), xdQ = bc<b>(dQ);
-                gv = fma(ciG[r * D + b], xdp, gv);
-                sdq = fma(cS[r * D + b], xdq, sdq);
-                cdq = fma(cCqq[r * D + b], xdq, cdq);
-                wdQ = fma(cG0[r * D + b], xdQ, wdQ);
-            });
-        }
-        WM_BLOCK {
-            sfor<0, D>([&](auto bcn) {
-                constexpr int b = decltype(bcn)::value;
-                const double xg = bc<b>(gv), xs = bc<b>(sdq), xn = cvec[48 + b];
-                g0g = fma(cG0[r * D + b], xg, g0g);
-                y.x = fma(Gti[b].x, xg, y.x); y.y = fma(Gti[b].y, xg, y.y);
-                u1.x = fma(Gti[b].x, xs, u1.x); u1.y = fma(Gti[b].y, xs, u1.y);
-                u2.x = fma(Gti[b].x, xn, u2.x); u2.y = fma(Gti[b].y, xn, u2.y);
-            });
-        }
-
-        // ---- V = Gti iGi0 ; CQQ = Gt~ - V Gti^T (70), in place in Gtl.  The rows of Gti go to the exchange buffer and
-        //      come back as group-uniform (broadcast) LDS reads: their registers are free while the product runs ----
+        cplx V[D];
         {
-            cplx V[D];
-            sfor_bb<0, D>([&](auto bcn) {          // iGi0 is symmetric: column b = row b, contiguous scalar loads
-                constexpr int b = decltype(bcn)::value;
-                cplx s = c_make(0.0, 0.0);
+            double ig[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) { const double x = kiG[b * D + k]; s.x = fma(Gti[k].x, x, s.x); s.y = fma(Gti[k].y, x, s.y); }
-                V[b] = s;
-            });
-            WM_BLOCK {
-                wave_lds_fence();
-                if (r < D) {
+            for (int b = 0; b < D; ++b) ig[b] = ciG[b];
+            {
+                double sr[D], cq[D], g0[D];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) xq[r * D + k] = Gti[k];
-                }
-                wave_lds_fence();
+                for (int b = 0; b < D; ++b) { sr[b] = cS[b]; cq[b] = cCqq[b]; g0[b] = cG0[b]; }
+                dpp_guard();
+                sfor<0, D>([&](auto bcn) {
+                    constexpr int b = decltype(bcn)::value;
+                    fmac_bc<b>(gv, dpv, ig[b]); fmac_bc<b>(sdq, dq, sr[b]); fmac_bc<b>(cdq, dq, cq[b]); fmac_bc<b>(wdQ, dQ, g0[b]);
+                });
+                dpp_guard();
+                sfor<0, D>([&](auto bcn) {
+                    constexpr int b = decltype(bcn)::value;
+                    fmac_bc<b>(g0g, gv, g0[b]);
+                    fmac_bc<b>(y.x, gv, Gti[b].x); fmac_bc<b>(y.y, gv, Gti[b].y);
+                    fmac_bc<b>(u1.x, sdq, Gti[b].x); fmac_bc<b>(u1.y, sdq, Gti[b].y);
+                    fmac_bc<b>(u2.x, sn1r, Gti[b].x); fmac_bc<b>(u2.y, sn1r, Gti[b].y);
+                });
             }
-            sfor_bb<0, D>([&](auto bcn) {
-                constexpr int b = decltype(bcn)::value;
-                cplx s = c_make(0.0, 0.0);
+            // ---- V = Gti iGi0 ; CQQ = Gt~ - V Gti^T (70), in place in Gtl ----
 #pragma unroll
-                for (int k = 0; k < D; ++k) s = c_fma(V[k], xq[b * D + k], s);
-                Gtl[b] = c_sub(Gtl[b], s);
+            for (int b = 0; b < D; ++b) V[b] = c_make(0.0, 0.0);
+            dpp_guard();
+            sfor<0, D>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+#pragma unroll
+                for (int b = 0; b < D; ++b) { fmac_bc<k>(V[b].x, ig[b], Gti[k].x); fmac_bc<k>(V[b].y, ig[b], Gti[k].y); }
             });
-            wave_lds_fence();
         }
+        sfor<0, D>([&](auto bcn) {
+            constexpr int b = decltype(bcn)::value;
+#pragma unroll
+            for (int k = 0; k < D; ++k) cfnma_bc<b>(Gtl[b], Gti[k], V[k]);
+        });
         if (W.cqq_out && active && r < D) {
             cplx *out = (cplx *)W.cqq_out + tr * (int64_t)DD + r * D;
 #pragma unroll
@@ -325,46 +345,68 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             ((cplx *)W.dvec_out)[tr * (int64_t)D + r] = c_make(u1.x - ihb * y.y, u1.y + ihb * (y.x + p0r));
 
         // ---- M'/(2 pi) = U^T (G0 + CQQ) U / (2 pi) (row i < d') and hat_v = U^T {u_dq, u_n1, w_dQ, w_n1, y} ----
-        cplx Mr[DP], hat[5], R[DP];
+        cplx Mr[DP], hat[5];
+        {
+            cplx R[DP];
+            double ur[DP], gre[D];
 #pragma unroll
-        for (int j = 0; j < DP; ++j) R[j] = c_make(0.0, 0.0);
-        sfor_bb<0, D>([&](auto bcn) {
-            constexpr int b = decltype(bcn)::value;
-            const double gre = cG0[r * D + b] + Gtl[b].x;
+            for (int j = 0; j < DP; ++j) { ur[j] = cU[j]; R[j] = c_make(0.0, 0.0); }
 #pragma unroll
-            for (int j = 0; j < DP; ++j) {
-                const double u = kU[b * DP + j];
-                R[j].x = fma(gre, u, R[j].x); R[j].y = fma(Gtl[b].y, u, R[j].y);
-            }
-        });
+            for (int b = 0; b < D; ++b) gre[b] = cG0[b] + Gtl[b].x;
+            dpp_guard();
+            sfor<0, D>([&](auto bcn) {
+                constexpr int b = decltype(bcn)::value;
 #pragma unroll
-        for (int j = 0; j < DP; ++j) Mr[j] = c_make(0.0, 0.0);
+                for (int j = 0; j < DP; ++j) { fmac_bc<b>(R[j].x, ur[j], gre[b]); fmac_bc<b>(R[j].y, ur[j], Gtl[b].y); }
+            });
+            double ut[D];
 #pragma unroll
-        for (int v = 0; v < 5; ++v) hat[v] = c_make(0.0, 0.0);
-        sfor_bb<0, D>([&](auto ac) {
-            constexpr int a = decltype(ac)::value;
-            const double ui = cUT[r * D + a];
+            for (int a = 0; a < D; ++a) ut[a] = cUT[a];
 #pragma unroll
-            for (int j = 0; j < DP; ++j) {
-                Mr[j].x = fma(ui, bc<a>(R[j].x), Mr[j].x); Mr[j].y = fma(ui, bc<a>(R[j].y), Mr[j].y);
-            }
-            hat[0].x = fma(ui, bc<a>(u1.x), hat[0].x); hat[0].y = fma(ui, bc<a>(u1.y), hat[0].y);
-            hat[1].x = fma(ui, bc<a>(u2.x), hat[1].x); hat[1].y = fma(ui, bc<a>(u2.y), hat[1].y);
-            hat[2].x = fma(ui, bc<a>(wdQ), hat[2].x);
-            hat[3].x = fma(ui, bc<a>(wn1r), hat[3].x);
-            hat[4].x = fma(ui, bc<a>(y.x), hat[4].x); hat[4].y = fma(ui, bc<a>(y.y), hat[4].y);
-        });
+            for (int j = 0; j < DP; ++j) Mr[j] = c_make(0.0, 0.0);
+#pragma unroll
+            for (int v = 0; v < 5; ++v) hat[v] = c_make(0.0, 0.0);
+            dpp_guard();
+            sfor<0, D>([&](auto ac) {
+                constexpr int a = decltype(ac)::value;
+#pragma unroll
+                for (int j = 0; j < DP; ++j) { fmac_bc<a>(Mr[j].x, R[j].x, ut[a]); fmac_bc<a>(Mr[j].y, R[j].y, ut[a]); }
+                fmac_bc<a>(hat[0].x, u1.x, ut[a]); fmac_bc<a>(hat[0].y, u1.y, ut[a]);
+                fmac_bc<a>(hat[1].x, u2.x, ut[a]); fmac_bc<a>(hat[1].y, u2.y, ut[a]);
+                fmac_bc<a>(hat[2].x, wdQ, ut[a]);
+                fmac_bc<a>(hat[3].x, wn1r, ut[a]);
+                fmac_bc<a>(hat[4].x, y.x, ut[a]); fmac_bc<a>(hat[4].y, y.y, ut[a]);
+            });
+        }
 #pragma unroll
         for (int j = 0; j < DP; ++j) Mr[j] = c_scale(Mr[j], W.inv_two_pi);
-        cplx sol[5];
+        // ---- M' rho = hat by row operations in the fixed pivot order (rows >= d' are zero and take no part); the matrix
+        //      and its five right-hand sides are one array: ms = [M'/(2 pi) | hat] (row r) ----
+        cplx ms[DP + 5];
 #pragma unroll
-        for (int v = 0; v < 5; ++v) sol[v] = hat[v];
-        cplx detM;
-        gauss_jordan_rows<DP, 5>(Mr, sol, r >= DP, r, rowbase, myk, src, detM);
-        // rho_v[k] sits in the pivot lane of step k: fetch it into lane k;  rho = M'^-1 hat (the 1/2pi of the scaling)
+        for (int j = 0; j < DP; ++j) ms[j] = Mr[j];
+#pragma unroll
+        for (int v = 0; v < 5; ++v) ms[DP + v] = hat[v];
+        cplx detM = c_make(1.0, 0.0), myinv = c_make(0.0, 0.0);
+        sfor<0, DP>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const double mag = c_abs2(ms[k]);
+            const int key = (r >= k && r < DP) ? __double2hiint(mag) : 0;
+            const int key_max = row_max(key), key_piv = bc_i32<k>(key);
+            if (weak_keys(key_piv, key_max) || key_piv == 0) weak = 1;      // (a zero or denormal pivot goes to the pivoted kernel)
+            const cplx piv = c_make(bc<k>(ms[k].x), bc<k>(ms[k].y));
+            detM = c_mul(detM, piv);
+            const cplx inv = c_inv_newton(piv);
+            const cplx f = c_mul(ms[k], inv);
+            const cplx m = c_make(r == k ? 0.0 : f.x, r == k ? 0.0 : f.y);
+            if (r == k) myinv = inv;
+            dpp_guard();
+            cfnma_inplace_range<k, k + 1, DP + 5>(ms, m);
+        });
+        // lane k holds rho_v[k];  rho = M'^-1 hat (the 1/2pi of the scaling)
         cplx rho[5];
 #pragma unroll
-        for (int v = 0; v < 5; ++v) rho[v] = c_scale(perm(src, sol[v]), W.inv_two_pi);
+        for (int v = 0; v < 5; ++v) rho[v] = c_scale(c_mul(ms[DP + v], myinv), W.inv_two_pi);
 
         // ---- bilinear forms a^T iM b and the scalar sums over the modes ----
         enum { UDQ = 0, UN1 = 1, WDQ = 2, WN1 = 3, Y = 4 };
@@ -404,23 +446,29 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             nacq = c_add(nacq, c_mul(c_make(0.0, ihb), Pq_n1));
             nacq.x += W.n2;
         }
+        const int weak_any = row_max(weak);       // the pivot lanes' verdicts, known to lane 0 of the trajectory
 
         // ---- one lane per trajectory: branch-tracked square roots, eqns (85) and (100) ----
-        if (r == 0 && active) {
+        if (r == 0 && active && weak_any && W.flags) {
+            W.flags[tr] = 1;                        // left to wm_kernel<false> (full partial pivoting) in the same stream
+            atomicAdd(W.flags + n, 1);
+        } else if (r == 0 && active) {
+            if (W.flags) W.flags[tr] = 0;
             cplx *prevA = (cplx *)W.detA + tr, *prevM = (cplx *)W.detM + tr;
-            const double sA = wm_track_sign(A.track, detA, prevA, W.sgnA + tr);
-            const double sM = wm_track_sign(A.track, detM, prevM, W.sgnM + tr);
+            const double sgA = wm_track_sign(A.track, detA, prevA, W.sgnA + tr);
+            const double sgM = wm_track_sign(A.track, detM, prevM, W.sgnM + tr);
             const cplx cpre = c_scale(c_sqrt(((const cplx *)A.st.c2)[tr]), A.st.sgn[tr]);
             const cplx phase = c_exp(c_make(0.0, A.st.act[tr] * ihb));
             cplx pre = c_mul(cpre, phase);
-            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detA)), sA));
+            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detA)), sgA));
             const double wgt = 1.0 / (A.mc_norm * A.probi[tr]);
             if (W.coef_out) {                   // eqn (75) without its x-dependent part, propagators.py:1408-1432
                 const cplx v = c_mul(pre, c_exp(c_make(eps - 0.5 * dqCdq, -ihb * piq_dq)));
                 ((cplx *)W.coef_out)[tr] = c_scale(v, W.pre_coef * wgt);
             }
-            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detM)), sM));
+            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detM)), sgM));
             const cplx cq = c_scale(c_mul(pre, c_exp(ex)), W.pre * wgt);          // (85) / (n P (2 pi hbar)^D)
+            double *acc = red + grp * 4;
             acc[0] += cq.x; acc[1] += cq.y;
             if (A.cq_out) ((cplx *)A.cq_out)[tr] = cq;
             if (A.has_nac) {
@@ -432,10 +480,6 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
         }
     }
     // ---- per-workgroup partial sums, fixed order ----
-    if (r == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[grp * 4 + i] = acc[i];
-    }
     __syncthreads();
     if (tid < 4) {
         double s = 0.0;

@@ -759,6 +759,7 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         self._detM = torch.ones(n, dtype=C128, device=dev)
         self._sgnA = torch.ones(n, dtype=F64, device=dev)
         self._sgnM = torch.ones(n, dtype=F64, device=dev)
+        self._wm_flags = torch.zeros(n + 1, dtype=torch.int32, device=dev)      # fixed-order pivots handed to the pivoted kernel
         self._gwm = lib.sc_wm_grid(n, self.dim)
         self._wpart = torch.zeros((self._gwm, 4), dtype=F64, device=dev)
         self._wm_step, self._wm_has_nac = -1, False
@@ -779,7 +780,7 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
             p0n1=self._wm_p0n1 if nb else 0.0, n2=self._wm_n2 if nb else 0.0,
             detA=ptr(self._detA), detM=ptr(self._detM), sgnA=ptr(self._sgnA), sgnM=ptr(self._sgnM),
             pre_coef=wm.pre_coef, scratch=ptr(self._wm_scratch),
-            scratch_bytes=0 if self._wm_scratch is None else self._wm_scratch.numel() * 8)
+            scratch_bytes=0 if self._wm_scratch is None else self._wm_scratch.numel() * 8, flags=ptr(self._wm_flags))
 
     def _remember_nac(self, potential):
         current, fp = self._nac_is_current(potential)

@@ -170,3 +170,21 @@ def test_rk4_step_matrix_of_constant_hessian_equals_staged_rk4():
     big = P.MolecularHarmonicPotential.from_arrays(np.zeros(20), np.float64(0.0), np.zeros(20), np.eye(20),
                                                    np.ones(20), np.zeros(20))
     assert big._step_matrix(dt) is None            # the kernel taking Phi holds D <= 16
+
+
+def test_dpp_hazards():
+    """The inline-assembly DPP multiply-adds of csrc/sc_row16.h bypass the compiler's hazard recogniser: no DPP operand
+    of the BUILT library may be read within two wait states of a VALU write of the same register."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "check_dpp_hazards", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                          "check_dpp_hazards.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    from semiclassical_amd import build
+    if not os.path.exists(chk.OBJDUMP) or not os.path.exists(chk.BUNDLER):
+        pytest.skip("ROCm LLVM tools not found")
+    bad, n_dpp = chk.scan(chk.disassemble(build.LIB))[:2]
+    assert n_dpp > 1000, "the disassembly did not reach the device code"
+    assert not bad, bad[:5]
