@@ -53,10 +53,23 @@ __device__ __forceinline__ double bc(double v) {
 // inline assembly.  `volatile`: the statements keep their source order -- the register pressure of a product loop is the
 // one written down, not what a list scheduler makes of several thousand independent multiply-adds.
 // HAZARD the compiler cannot see: a VGPR written by a VALU instruction must not be read as the DPP operand by one of the
-// next two instructions.  The DPP operands of every loop below are arrays completed in an earlier phase; `dpp_guard()`
-// (s_nop 1) separates a phase from the code that produced its operands, and tests/test_host.py::test_dpp_hazards scans
-// the disassembly of the built library for any DPP read closer than that to a write of the same register.
-__device__ __forceinline__ void dpp_guard() { asm volatile("s_nop 1"); }
+// next two instructions.  The DPP operands of every loop below are arrays completed in an earlier phase; `dpp_guard(...)`
+// separates a phase from the code that produced its operands, and tests/test_host.py::test_dpp_hazards scans the
+// disassembly of the built library for any DPP read closer than that to a write of the same register.
+// `dpp_guard(operands...)` first pins every operand (scalar, complex or array) into its registers -- an empty volatile asm
+// with the value as in/out operand: the compiler has to have computed or copied it BEFORE that point -- and then waits.
+__device__ __forceinline__ void dpp_pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void dpp_pin(cplx &x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
+template <class T, int N>
+__device__ __forceinline__ void dpp_pin(T (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) dpp_pin(x[i]);
+}
+template <class... T>
+__device__ __forceinline__ void dpp_guard(T &...operands) {
+    (dpp_pin(operands), ...);
+    asm volatile("s_nop 1");
+}
 
 template <int K>
 __device__ __forceinline__ void fmac_bc(double &acc, const double &b, const double &a) {      // acc += b[K] * a

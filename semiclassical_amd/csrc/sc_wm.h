@@ -30,5 +30,9 @@ __device__ __forceinline__ double wm_track_sign(int track, cplx z, cplx *prev, d
     return s;
 }
 
+// doubles per trajectory the register kernel hands to its tail kernel through wc->scratch: detA, detM, ex, (eps, dq.Cqq.dq),
+// (pi_q.dq, -), nacQ, nacq, nacqQ
+#define WM_TAIL_FIELDS 16
+
 // sc_wm_small.hip: returns 1 and launches if (D, d') has a register-resident instantiation, 0 if not, < 0 on error
 int sc_wm_launch_small(const WmArgs &a, int grid, hipStream_t s);

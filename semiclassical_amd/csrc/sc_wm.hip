@@ -569,7 +569,9 @@ static bool wm_has_small_kernel(int D, int dp) {
 
 extern "C" int64_t sc_wm_scratch_bytes(int64_t n, int32_t dim, int32_t dprime) {
     if (dim < 1 || dprime < 1 || dprime > dim) return -1;
-    if (wm_has_small_kernel(dim, dprime) || wm_lds_bytes(dim, dprime) <= 160 * 1024) return 0;
+    // register kernel: the per-trajectory scalars it hands to its tail kernel
+    if (wm_has_small_kernel(dim, dprime)) return (int64_t)WM_TAIL_FIELDS * 8 * (n > 0 ? n : 0);
+    if (wm_lds_bytes(dim, dprime) <= 160 * 1024) return 0;
     return (int64_t)wm_scratch_stride(dim, dprime) * wm_scratch_grid(n);
 }
 
@@ -599,12 +601,17 @@ extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const
         return sc_check_launch("sc_wm_correlate");
     };
     if (wm_has_small_kernel(D, dp)) {
+        if (!wc->scratch || wc->scratch_bytes < sc_wm_scratch_bytes(st->n, D, dp))
+            return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: D=%d d'=%d needs a scratch buffer of %lld B (sc_wm_scratch_bytes), "
+                           "got %lld", D, dp, (long long)sc_wm_scratch_bytes(st->n, D, dp), (long long)wc->scratch_bytes);
+        a.scratch = wc->scratch;
         if (wc->flags && hipMemsetAsync(wc->flags + st->n, 0, sizeof(int32_t), s) != hipSuccess)
             return sc_check_launch("sc_wm_correlate (flag counter)");
         const int rc = sc_wm_launch_small(a, grid, s);
         if (rc < 0) return rc;
         if (rc != 0) {
             // slots of the re-run: written by it (zeros from its idle workgroups), or cleared here when there is none
+            a.scratch = nullptr;
             a.partials = partials + 4 * (size_t)grid;
             a.npartials = WM_RERUN_GRID;
             if (!wc->flags) {

@@ -45,7 +45,7 @@ struct WmSmallLayout {
     static constexpr int PB = 2 * E + 2;             // doubles per lane of the parked BQ' row (pitch: 16-byte aligned, odd in 16-byte units)
     static constexpr int xt = D * EP + 16;           // transposition buffer (+16: lanes beyond the matrix read, never use)
     static constexpr int xbuf = (xt > 16 * PB ? xt : 16 * PB) + (xt > 16 * PB ? xt & 1 : 0);   // doubles per trajectory
-    static constexpr size_t bytes = (size_t)n_const * 8 + (size_t)16 * xbuf * 8 + 16 * 4 * 8;
+    static constexpr size_t bytes = (size_t)n_const * 8 + (size_t)16 * xbuf * 8;
 };
 
 #ifndef SC_WM_SMALL_OCC
@@ -55,6 +55,30 @@ struct WmSmallLayout {
 #ifndef SC_WM_FORCE_WEAK
 #define SC_WM_FORCE_WEAK 0     // 1: variant library that flags EVERY trajectory (tests of the pivoted fallback)
 #endif
+
+// sum over the lanes k < N of the 16-lane row of every element of t (result in all lanes): t_m <- sum_k t_m[k]
+template <int N, int M>
+__device__ __forceinline__ void sum_rows(double (&t)[M], const double &one) {
+    double s[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) s[m] = 0.0;
+    dpp_guard(t);
+    sfor<0, N>([&](auto kc) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) fmac_bc<decltype(kc)::value>(s[m], t[m], one);
+    });
+#pragma unroll
+    for (int m = 0; m < M; ++m) t[m] = s[m];
+}
+template <int N, int M>
+__device__ __forceinline__ void sum_rows(cplx (&t)[M], const double &one) {
+    double s[2 * M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) { s[2 * m] = t[m].x; s[2 * m + 1] = t[m].y; }
+    sum_rows<N>(s, one);
+#pragma unroll
+    for (int m = 0; m < M; ++m) t[m] = c_make(s[2 * m], s[2 * m + 1]);
+}
 
 // |pivot|^2 more than 2^8 below the largest candidate: hand the trajectory to the pivoted kernel
 __device__ __forceinline__ bool weak_keys(int key_pivot, int key_max) { return key_max - key_pivot > (8 << 20); }
@@ -80,8 +104,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     double *sBi = ls;   ls += 16 * DP;
     double *sCst = ls;  ls += 2 * 16 * E;
     double *cvec = ls;  ls += 8 * 16;            // [q0 | p0 | n1 | s_n1 | w_n1 | crow | - | -][16]
-    double *xall = ls;  ls += 16 * L::xbuf;
-    double *red = ls;
+    double *xall = ls;
 
     // ---- stage the per-lane rows of the constants (once per workgroup) ----
     for (int e = tid; e < 16 * D; e += 256) {
@@ -120,7 +143,6 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     __syncthreads();
 
     double *xr = xall + grp * L::xbuf;          // transposition buffer of this trajectory
-    if (r < 4) red[grp * 4 + r] = 0.0;          // running sums of this 16-lane row's trajectories (lane 0 adds, fixed order)
     const int64_t n = A.st.n, stride = (int64_t)gridDim.x * 16;
     for (int64_t t0 = (int64_t)blockIdx.x * 16; t0 < n; t0 += stride) {
         const bool active = t0 + grp < n;
@@ -158,7 +180,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             for (int j = 0; j < DP; ++j) ur[j] = cU[j];
 #pragma unroll
             for (int j = 0; j < E; ++j) { Mq[j] = 0.0; Mp[j] = 0.0; }
-            dpp_guard();
+            dpp_guard(ur);
             sfor<0, D>([&](auto bcn) {
                 constexpr int b = decltype(bcn)::value;
 #pragma unroll
@@ -198,7 +220,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             for (int b = 0; b < D; ++b) gt[b] = cGt[b];
 #pragma unroll
             for (int j = 0; j < E; ++j) Tq[j] = 0.0;
-            dpp_guard();
+            dpp_guard(Mq);
             sfor<0, D>([&](auto bcn) {
                 constexpr int b = decltype(bcn)::value;
 #pragma unroll
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             double cs[D], ca[D], cb[D];
 #pragma unroll
             for (int a = 0; a < D; ++a) { cs[a] = MqT[a] * sA; ca[a] = MpT[a] * fa; cb[a] = MqT[a] * fb; }
-            dpp_guard();
+            dpp_guard(Tq, Mq, Mp);
             sfor<0, D>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
 #pragma unroll
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
         // ---- W (A'/s) = BQ' by column operations in the fixed pivot order 0 .. e-1 (see the header) ----
         cplx detA = c_make(1.0, 0.0);
         int weak = SC_WM_FORCE_WEAK;
-        dpp_guard();
+        dpp_guard(rowA, rowB);
         sfor<0, E>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             // candidates of partial pivoting: entries k .. e-1 of the pivot lane's row
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             // the pivot lane's own entries below the diagonal are never read again: its multiplier is zeroed so that
             // the in-place update below does not change what the other lanes read from it
             const cplx tA = c_make(r == k ? 0.0 : tAf.x, r == k ? 0.0 : tAf.y);
-            dpp_guard();
+            dpp_guard(rowA, rowB);
             sfor<k + 1, E>([&](auto ic) { cfnma_bc<k>(rowB[decltype(ic)::value], rowA[decltype(ic)::value], tB); });
             cfnma_inplace_range<k, k + 1, E>(rowA, tA);
         });
@@ -271,7 +293,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             for (int k = 0; k < E; ++k) { Wm[k] = c_scale(rowB[k], sA); BQ[k] = park[k]; }
 #pragma unroll
             for (int b = 0; b < D; ++b) Gtl[b] = c_make(cGt[b], 0.0);
-            dpp_guard();
+            dpp_guard(BQ, Gtl);
             sfor<0, D>([&](auto bcn) {
                 constexpr int b = decltype(bcn)::value;
 #pragma unroll
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             for (int k = 0; k < DP; ++k) { br[k] = cBr[k]; bi[k] = cBi[k]; }
 #pragma unroll
             for (int b = 0; b < D; ++b) Gti[b] = c_make(0.0, 0.0);
-            dpp_guard();
+            dpp_guard(br, bi);
             sfor<0, D>([&](auto bcn) {
                 constexpr int b = decltype(bcn)::value;
 #pragma unroll
@@ -307,30 +329,32 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
                 double sr[D], cq[D], g0[D];
 #pragma unroll
                 for (int b = 0; b < D; ++b) { sr[b] = cS[b]; cq[b] = cCqq[b]; g0[b] = cG0[b]; }
-                dpp_guard();
+                dpp_guard(dpv, dq, dQ);
                 sfor<0, D>([&](auto bcn) {
                     constexpr int b = decltype(bcn)::value;
                     fmac_bc<b>(gv, dpv, ig[b]); fmac_bc<b>(sdq, dq, sr[b]); fmac_bc<b>(cdq, dq, cq[b]); fmac_bc<b>(wdQ, dQ, g0[b]);
                 });
-                dpp_guard();
+                double sn1 = sn1r;
+                dpp_guard(gv, sdq, sn1);
                 sfor<0, D>([&](auto bcn) {
                     constexpr int b = decltype(bcn)::value;
                     fmac_bc<b>(g0g, gv, g0[b]);
                     fmac_bc<b>(y.x, gv, Gti[b].x); fmac_bc<b>(y.y, gv, Gti[b].y);
                     fmac_bc<b>(u1.x, sdq, Gti[b].x); fmac_bc<b>(u1.y, sdq, Gti[b].y);
-                    fmac_bc<b>(u2.x, sn1r, Gti[b].x); fmac_bc<b>(u2.y, sn1r, Gti[b].y);
+                    fmac_bc<b>(u2.x, sn1, Gti[b].x); fmac_bc<b>(u2.y, sn1, Gti[b].y);
                 });
             }
             // ---- V = Gti iGi0 ; CQQ = Gt~ - V Gti^T (70), in place in Gtl ----
 #pragma unroll
             for (int b = 0; b < D; ++b) V[b] = c_make(0.0, 0.0);
-            dpp_guard();
+            dpp_guard(ig);
             sfor<0, D>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
 #pragma unroll
                 for (int b = 0; b < D; ++b) { fmac_bc<k>(V[b].x, ig[b], Gti[k].x); fmac_bc<k>(V[b].y, ig[b], Gti[k].y); }
             });
         }
+        dpp_guard(Gti);
         sfor<0, D>([&](auto bcn) {
             constexpr int b = decltype(bcn)::value;
 #pragma unroll
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             for (int j = 0; j < DP; ++j) { ur[j] = cU[j]; R[j] = c_make(0.0, 0.0); }
 #pragma unroll
             for (int b = 0; b < D; ++b) gre[b] = cG0[b] + Gtl[b].x;
-            dpp_guard();
+            dpp_guard(ur);
             sfor<0, D>([&](auto bcn) {
                 constexpr int b = decltype(bcn)::value;
 #pragma unroll
@@ -366,7 +390,8 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             for (int j = 0; j < DP; ++j) Mr[j] = c_make(0.0, 0.0);
 #pragma unroll
             for (int v = 0; v < 5; ++v) hat[v] = c_make(0.0, 0.0);
-            dpp_guard();
+            double wn1 = wn1r;
+            dpp_guard(R, u1, u2, wdQ, wn1, y);
             sfor<0, D>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
 #pragma unroll
@@ -374,7 +399,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
                 fmac_bc<a>(hat[0].x, u1.x, ut[a]); fmac_bc<a>(hat[0].y, u1.y, ut[a]);
                 fmac_bc<a>(hat[1].x, u2.x, ut[a]); fmac_bc<a>(hat[1].y, u2.y, ut[a]);
                 fmac_bc<a>(hat[2].x, wdQ, ut[a]);
-                fmac_bc<a>(hat[3].x, wn1r, ut[a]);
+                fmac_bc<a>(hat[3].x, wn1, ut[a]);
                 fmac_bc<a>(hat[4].x, y.x, ut[a]); fmac_bc<a>(hat[4].y, y.y, ut[a]);
             });
         }
@@ -400,7 +425,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             const cplx f = c_mul(ms[k], inv);
             const cplx m = c_make(r == k ? 0.0 : f.x, r == k ? 0.0 : f.y);
             if (r == k) myinv = inv;
-            dpp_guard();
+            dpp_guard(ms);
             cfnma_inplace_range<k, k + 1, DP + 5>(ms, m);
         });
         // lane k holds rho_v[k];  rho = M'^-1 hat (the 1/2pi of the scaling)
@@ -408,24 +433,27 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
 #pragma unroll
         for (int v = 0; v < 5; ++v) rho[v] = c_scale(c_mul(ms[DP + v], myinv), W.inv_two_pi);
 
-        // ---- bilinear forms a^T iM b and the scalar sums over the modes ----
+        // ---- bilinear forms a^T iM b and the scalar sums over the modes: the per-lane terms first, then all sums over the
+        //      lanes together, each as a chain of fused broadcast multiply-adds with 1.0 (lanes k < d' resp. k < D only: no
+        //      masking, and a third of the instructions of the rotate-and-add reduction) ----
         enum { UDQ = 0, UN1 = 1, WDQ = 2, WN1 = 3, Y = 4 };
-        auto form = [&](int a, int b) {
-            const cplx t = r < DP ? c_mul(hat[a], rho[b]) : c_make(0.0, 0.0);
-            return c_make(row_sum(t.x), row_sum(t.y));
-        };
+        double one = 1.0;
+        asm volatile("" : "+v"(one));
         const double piq = p0r - g0g;                                            // (72)
-        const double dqCdq = row_sum(dq * cdq), dqCn1 = row_sum(dq * crowr), dQGdQ = row_sum(dQ * wdQ);
-        const double dQGn1 = row_sum(dQ * wn1r), piq_dq = row_sum(piq * dq), piq_n1 = row_sum(piq * n1r);
-        const double p0_dQ = row_sum(p0r * dQ);
-        const double eps = -0.5 * ihb * ihb * row_sum(dpv * gv);                 // (74), b0 = 0
-        const cplx yy = form(Y, Y);
+        cplx f6[6] = {c_mul(hat[Y], rho[Y]), c_mul(hat[UDQ], rho[UDQ]), c_mul(hat[WDQ], rho[WDQ]),
+                      c_mul(hat[UDQ], rho[WDQ]), c_mul(hat[UDQ], rho[Y]), c_mul(hat[WDQ], rho[Y])};
+        double s8[8] = {dq * cdq, dq * crowr, dQ * wdQ, dQ * wn1r, piq * dq, piq * n1r, p0r * dQ, dpv * gv};
+        sum_rows<DP>(f6, one);
+        sum_rows<D>(s8, one);
+        const double dqCdq = s8[0], dqCn1 = s8[1], dQGdQ = s8[2], dQGn1 = s8[3], piq_dq = s8[4], piq_n1 = s8[5], p0_dQ = s8[6];
+        const double eps = -0.5 * ihb * ihb * s8[7];                             // (74), b0 = 0
+        const cplx yy = f6[0];
         const cplx gamma = c_make(eps - 0.5 * ihb * ihb * yy.x, -0.5 * ihb * ihb * yy.y);   // (84)
-        const cplx q_rqq_q = c_sub(c_make(dqCdq, 0), form(UDQ, UDQ));
-        const cplx Q_rQQ_Q = c_sub(c_make(dQGdQ, 0), form(WDQ, WDQ));
-        const cplx q_rqQ_Q = form(UDQ, WDQ);
-        const cplx Pq_dq = c_sub(c_make(piq_dq, 0), form(UDQ, Y));
-        const cplx PQ_dQ = c_add(c_make(p0_dQ, 0), form(WDQ, Y));
+        const cplx q_rqq_q = c_sub(c_make(dqCdq, 0), f6[1]);
+        const cplx Q_rQQ_Q = c_sub(c_make(dQGdQ, 0), f6[2]);
+        const cplx q_rqQ_Q = f6[3];
+        const cplx Pq_dq = c_sub(c_make(piq_dq, 0), f6[4]);
+        const cplx PQ_dQ = c_add(c_make(p0_dQ, 0), f6[5]);
         cplx ex = gamma;
         ex = c_sub(ex, c_scale(q_rqq_q, 0.5));
         ex = c_sub(ex, c_scale(Q_rQQ_Q, 0.5));
@@ -434,58 +462,74 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
         ex = c_add(ex, c_mul(c_make(0.0, ihb), PQ_dQ));
         cplx nacQ = c_make(0, 0), nacq = c_make(0, 0), nacqQ = c_make(0, 0);
         if (A.has_nac) {
-            nacqQ = form(UN1, WN1);
-            const cplx PQ_n1 = c_add(c_make(W.p0n1, 0), form(WN1, Y));
-            const cplx Pq_n1 = c_sub(c_make(piq_n1, 0), form(UN1, Y));
-            nacQ = c_sub(c_make(dQGn1, 0), form(WDQ, WN1));                      // dQ^T RQQ n1
-            nacQ = c_sub(nacQ, form(UDQ, WN1));                                  // - dq^T RqQ n1
+            cplx f7[7] = {c_mul(hat[UN1], rho[WN1]), c_mul(hat[WN1], rho[Y]), c_mul(hat[UN1], rho[Y]), c_mul(hat[WDQ], rho[WN1]),
+                          c_mul(hat[UDQ], rho[WN1]), c_mul(hat[UDQ], rho[UN1]), c_mul(hat[UN1], rho[WDQ])};
+            sum_rows<DP>(f7, one);
+            nacqQ = f7[0];
+            const cplx PQ_n1 = c_add(c_make(W.p0n1, 0), f7[1]);
+            const cplx Pq_n1 = c_sub(c_make(piq_n1, 0), f7[2]);
+            nacQ = c_sub(c_make(dQGn1, 0), f7[3]);                               // dQ^T RQQ n1
+            nacQ = c_sub(nacQ, f7[4]);                                           // - dq^T RqQ n1
             nacQ = c_add(nacQ, c_mul(c_make(0.0, -ihb), PQ_n1));
             nacQ.x += W.n2;
-            nacq = c_sub(c_make(dqCn1, 0), form(UDQ, UN1));                      // dq^T Rqq n1
-            nacq = c_sub(nacq, form(UN1, WDQ));                                  // - n1^T RqQ dQ
+            nacq = c_sub(c_make(dqCn1, 0), f7[5]);                               // dq^T Rqq n1
+            nacq = c_sub(nacq, f7[6]);                                           // - n1^T RqQ dQ
             nacq = c_add(nacq, c_mul(c_make(0.0, ihb), Pq_n1));
             nacq.x += W.n2;
         }
         const int weak_any = row_max(weak);       // the pivot lanes' verdicts, known to lane 0 of the trajectory
 
-        // ---- one lane per trajectory: branch-tracked square roots, eqns (85) and (100) ----
-        if (r == 0 && active && weak_any && W.flags) {
-            W.flags[tr] = 1;                        // left to wm_kernel<false> (full partial pivoting) in the same stream
-            atomicAdd(W.flags + n, 1);
-        } else if (r == 0 && active) {
-            if (W.flags) W.flags[tr] = 0;
-            cplx *prevA = (cplx *)W.detA + tr, *prevM = (cplx *)W.detM + tr;
-            const double sgA = wm_track_sign(A.track, detA, prevA, W.sgnA + tr);
-            const double sgM = wm_track_sign(A.track, detM, prevM, W.sgnM + tr);
-            const cplx cpre = c_scale(c_sqrt(((const cplx *)A.st.c2)[tr]), A.st.sgn[tr]);
-            const cplx phase = c_exp(c_make(0.0, A.st.act[tr] * ihb));
-            cplx pre = c_mul(cpre, phase);
-            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detA)), sgA));
-            const double wgt = 1.0 / (A.mc_norm * A.probi[tr]);
-            if (W.coef_out) {                   // eqn (75) without its x-dependent part, propagators.py:1408-1432
-                const cplx v = c_mul(pre, c_exp(c_make(eps - 0.5 * dqCdq, -ihb * piq_dq)));
-                ((cplx *)W.coef_out)[tr] = c_scale(v, W.pre_coef * wgt);
+        // ---- hand-over to wm_tail_kernel (one THREAD per trajectory does the branch-tracked square roots, the exponentials
+        //      and eqns (85), (100): in here that scalar code would run with 4 of 64 lanes active) ----
+        if (r == 0 && active) {
+            if (W.flags) {
+                W.flags[tr] = weak_any;             // 1: left to wm_kernel<false> (full partial pivoting) in the same stream
+                if (weak_any) atomicAdd(W.flags + n, 1);
             }
-            pre = c_mul(pre, c_scale(c_inv(c_sqrt(detM)), sgM));
-            const cplx cq = c_scale(c_mul(pre, c_exp(ex)), W.pre * wgt);          // (85) / (n P (2 pi hbar)^D)
-            double *acc = red + grp * 4;
-            acc[0] += cq.x; acc[1] += cq.y;
-            if (A.cq_out) ((cplx *)A.cq_out)[tr] = cq;
-            if (A.has_nac) {
-                cplx kq = c_mul(c_add(nacqQ, c_mul(nacQ, nacq)), cq);             // (100)
-                kq = c_scale(kq, ihb * ihb);
-                acc[2] += kq.x; acc[3] += kq.y;
-                if (A.kq_out) ((cplx *)A.kq_out)[tr] = kq;
-            }
+            double2 *out = (double2 *)(A.scratch + tr * WM_TAIL_FIELDS);
+            out[0] = detA; out[1] = detM; out[2] = ex; out[3] = make_double2(eps, dqCdq);
+            out[4] = make_double2(piq_dq, 0.0); out[5] = nacQ; out[6] = nacq; out[7] = nacqQ;
         }
     }
-    // ---- per-workgroup partial sums, fixed order ----
-    __syncthreads();
-    if (tid < 4) {
-        double s = 0.0;
-        for (int g = 0; g < 16; ++g) s += red[g * 4 + tid];
-        A.partials[(size_t)blockIdx.x * 4 + tid] = s;
+}
+
+// One thread per trajectory: trackers of sqrt(detA), sqrt(detM) (propagators.py:1336, 1389), eqn (85) and (100), export
+// of eqn (75); per-workgroup partial sums in a fixed order.  Trajectories flagged for the pivoted re-run are skipped.
+__global__ __launch_bounds__(256) void wm_tail_kernel(WmArgs A) {
+    __shared__ double red[4 * 4];
+    const sc_wm_consts &W = A.wc;
+    const double ihb = 1.0 / SC_HBAR;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t tr = (int64_t)blockIdx.x * 256 + threadIdx.x; tr < A.st.n; tr += (int64_t)gridDim.x * 256) {
+        if (W.flags && W.flags[tr]) continue;
+        const double2 *in = (const double2 *)(A.scratch + tr * WM_TAIL_FIELDS);
+        const cplx detA = in[0], detM = in[1], ex = in[2], nacQ = in[5], nacq = in[6], nacqQ = in[7];
+        const double eps = in[3].x, dqCdq = in[3].y, piq_dq = in[4].x;
+        cplx *prevA = (cplx *)W.detA + tr, *prevM = (cplx *)W.detM + tr;
+        const double sgA = wm_track_sign(A.track, detA, prevA, W.sgnA + tr);
+        const double sgM = wm_track_sign(A.track, detM, prevM, W.sgnM + tr);
+        const cplx cpre = c_scale(c_sqrt(((const cplx *)A.st.c2)[tr]), A.st.sgn[tr]);
+        const cplx phase = c_exp(c_make(0.0, A.st.act[tr] * ihb));
+        cplx pre = c_mul(cpre, phase);
+        pre = c_mul(pre, c_scale(c_inv(c_sqrt(detA)), sgA));
+        const double wgt = 1.0 / (A.mc_norm * A.probi[tr]);
+        if (W.coef_out) {                   // eqn (75) without its x-dependent part, propagators.py:1408-1432
+            const cplx v = c_mul(pre, c_exp(c_make(eps - 0.5 * dqCdq, -ihb * piq_dq)));
+            ((cplx *)W.coef_out)[tr] = c_scale(v, W.pre_coef * wgt);
+        }
+        pre = c_mul(pre, c_scale(c_inv(c_sqrt(detM)), sgM));
+        const cplx cq = c_scale(c_mul(pre, c_exp(ex)), W.pre * wgt);          // (85) / (n P (2 pi hbar)^D)
+        acc[0] += cq.x; acc[1] += cq.y;
+        if (A.cq_out) ((cplx *)A.cq_out)[tr] = cq;
+        if (A.has_nac) {
+            cplx kq = c_mul(c_add(nacqQ, c_mul(nacQ, nacq)), cq);             // (100)
+            kq = c_scale(kq, ihb * ihb);
+            acc[2] += kq.x; acc[3] += kq.y;
+            if (A.kq_out) ((cplx *)A.kq_out)[tr] = kq;
+        }
     }
+    block_sum<4>(acc, red);
+    if (threadIdx.x < 4) A.partials[(size_t)blockIdx.x * 4 + threadIdx.x] = acc[threadIdx.x];
 }
 
 template <int D, int DP>
@@ -495,7 +539,10 @@ int launch(const WmArgs &a, int grid, hipStream_t s) {
         hipSuccess)
         return sc_check_launch("sc_wm_correlate (LDS attribute)");
     hipLaunchKernelGGL((wm_small_kernel<D, DP>), dim3(grid), dim3(256), lds, s, a);
-    const int rc = sc_check_launch("sc_wm_correlate (register-resident kernel)");
+    int rc = sc_check_launch("sc_wm_correlate (register-resident kernel)");
+    if (rc != SC_OK) return rc;
+    hipLaunchKernelGGL(wm_tail_kernel, dim3(grid), dim3(256), 0, s, a);        // partials[0 .. grid)
+    rc = sc_check_launch("sc_wm_correlate (scalar tails)");
     return rc == SC_OK ? 1 : rc;
 }
 

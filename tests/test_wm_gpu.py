@@ -148,7 +148,60 @@ def test_wm_beyond_lds_runs_on_global_scratch(D):
 
 def test_wm_scratch_query_and_refusal():
     from semiclassical_amd._lib import lib
-    assert lib.sc_wm_scratch_bytes(1000, 12, 6) == 0          # register kernel
+    assert lib.sc_wm_scratch_bytes(1000, 12, 6) == 1000 * 128  # register kernel: scalars handed to its tail kernel
     assert lib.sc_wm_scratch_bytes(1000, 20, 20) == 0         # LDS kernel
     assert lib.sc_wm_scratch_bytes(1000, 60, 60) > 0
     assert lib.sc_wm_scratch_bytes(1000, 5, 6) == -1
+
+
+@pytest.mark.parametrize("D,zero_modes", [(5, 0), (12, 6)])
+def test_wm_weak_fixed_order_pivots_are_rerun_with_pivoting(D, zero_modes):
+    """The register kernel eliminates in a FIXED pivot order and hands a trajectory to the pivoted LDS kernel when a pivot is
+    more than 16 x smaller than what partial pivoting would have chosen.  Large, random momentum blocks Mpq, Mpp make the
+    imaginary part i/hbar (2G - H) of the Filinov matrix dominate its diagonally dominant real part, so that the fixed
+    order meets weak pivots for part of the trajectories: results must equal the oracle's (torch LU) for ALL of them,
+    trackers bit-exact, and the flags must say that both kernels took part."""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(7 + D)
+    omega = torch.from_numpy(np.sort(rng.uniform(600, 2500, D)) / 219474.63)
+    nac = torch.from_numpy(rng.normal(0, 1e-3, D))
+    q0, p0 = torch.from_numpy(rng.normal(0, 1.0, D)), torch.zeros(D)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    w = omega.numpy() * rng.uniform(0.7, 1.4, D)
+    w[:zero_modes] = 0.0
+    G = torch.from_numpy(Q @ np.diag(w) @ Q.T)
+    G = 0.5 * (G + G.T)
+    alpha, n, dt, E0 = 0.05, 400, 2.0, 0.0
+    ref = orc.WMOracle(G, G, alpha, alpha)
+    prop = PR.WaltonManolopoulosPropagator(G, G, alpha, alpha, device="cuda")
+    torch.manual_seed(3)
+    ref.initial_conditions(q0, p0, G, ntraj=n)
+    prop.set_initial_conditions(q0, p0, G, ref.zi, ref.probi)
+    gen = torch.Generator().manual_seed(11)
+    y = ref.y.clone()
+    eye = torch.eye(D).unsqueeze(2)
+    scale = [1.0, 1.0, 30.0, 30.0]                       # Mqq, Mqp ~ 1; Mpq, Mpp ~ 30
+    for k in range(4):
+        blk = scale[k] * ((eye if k in (0, 3) else 0.0) + 0.5 * torch.randn(D, D, n, generator=gen))
+        y[2 * D + k * D * D: 2 * D + (k + 1) * D * D] = blk.reshape(D * D, n)
+    ref.y = y
+    prop.y = y.cuda()
+    chi = torch.zeros(D)                                 # harmonic: the blocks stay what they are up to the linear flow
+    rc, rk = orc.run_loop(ref, orc.MorseOracle(omega, chi.clone(), nac), dt, 3, E0)
+    opot = P.MorsePotential(omega, chi.clone(), nac)
+    c, k = np.zeros(3, dtype=complex), np.zeros(3, dtype=complex)
+    flagged = []
+    for t in range(3):
+        c[t], k[t] = prop.autocorrelation(E0), prop.ic_correlation(opot, E0)
+        prop.step(opot, dt)
+        torch.cuda.synchronize()
+        flagged.append(int(prop._wm_flags[-1].item()))
+        assert flagged[-1] == int(prop._wm_flags[:-1].sum().item())
+    # t = 0 terms were produced before the state was replaced (identity blocks): compare the steps behind it
+    assert cases.rel_err(c[1:], rc[1:]) < TOL and cases.rel_err(k[1:], rk[1:]) < TOL, (c, rc)
+    for key, sgn in (("detA", prop._sgnA), ("detM", prop._sgnM)):
+        assert np.array_equal(cnp(sgn), ref.tracker.signs(key).real.numpy()), key
+    assert cases.rel_err(cnp(prop._detA), ref.tracker.state["detA"]["previous"].numpy()) < TOL
+    assert 0 < max(flagged) < n, flagged                  # some trajectories re-run with pivoting, some not
