@@ -275,8 +275,9 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
         const char *which = getenv("SC_FAST_KERNEL");
         if (which && which[0] == 'r') return sc_launch_step_rw(a, (hipStream_t)stream);
 #endif
-        // D <= 16: the small-D kernels pivot over the whole row (no flags, no cursor, no fix-up launch)
-        bool small = D <= 16;
+        // 13 <= D <= 16: hk_step_w16_kernel pivots over the whole row (no flags, no cursor, no fix-up launch); D <= 12:
+        // hk_step_sep16_kernel eliminates in a fixed order and flags weak pivots like the 256-thread kernel
+        bool small = D > SC_SEP16_MAX_D && D <= 16;
 #ifdef SC_TUNING
         if (getenv("SC_NO_WAVE_KERNEL")) small = false;      // the 256-thread kernel is forced: it needs flags and cursor
 #endif
@@ -297,8 +298,20 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     hipStream_t s = (hipStream_t)stream;
     // constant Hessian, D <= 16 and the step matrix Phi(dt) at hand: the register kernel of sc_hk_step_lin.hip
     if (dense && D <= 16 && (mode == 1 || (mode == 0 && pot->lin_prop && pot->lin_dt == dt))) {
+        if (st->flags && hipMemsetAsync(st->flags + st->n, 0, sizeof(int32_t), s) != hipSuccess)
+            return sc_check_launch("sc_hk_step (flag counter)");
         const int rc = sc_launch_step_lin(a, grid, s);
-        if (rc != 0) return rc < 0 ? rc : SC_OK;
+        if (rc < 0) return rc;
+        if (rc != 0) {
+            if (!st->flags) return SC_OK;
+            // determinants the fixed pivot order was too weak for (normally none): fully pivoted fix-up, same stream
+            a.mode = mode | 0x200;
+            a.epart = nullptr;
+            if (hipFuncSetAttribute((const void *)hk_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return sc_check_launch("sc_hk_step (LDS attribute)");
+            hipLaunchKernelGGL(hk_step_kernel<true>, dim3(grid), dim3(threads), lds, s, a);
+            return sc_check_launch("sc_hk_step (fix-up)");
+        }
     }
     if (dense) {
         if (hipFuncSetAttribute((const void *)hk_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

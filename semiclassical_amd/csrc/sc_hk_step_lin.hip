@@ -21,14 +21,18 @@
 #ifndef SC_LIN_OCC
 #define SC_LIN_OCC 2      // waves per SIMD the kernel is compiled for
 #endif
+#ifndef SC_LIN_FORCE_FIXUP
+#define SC_LIN_FORCE_FIXUP 0     // 1: variant library that hands every determinant to the pivoted fix-up launch
+#endif
 
 namespace {
 
 template <int D, int DP, bool DIAG>
 struct LinLayout {
-    // doubles: H rows [16][D], Phi rows [16][4 D], per-lane vectors [8][16]; complex rows L1, L2 [16][D] (dense widths)
+    // doubles: H rows [16][D], Phi rows [16][4 D], per-lane vectors [8][16]; complex rows L1, L2 [16][D] and R1, R2 [16][d']
+    // (dense widths)
     static constexpr int n_real = 16 * D + 16 * 4 * D + 8 * 16;
-    static constexpr int n_cplx = DIAG ? 0 : 2 * 16 * D;
+    static constexpr int n_cplx = DIAG ? 0 : 2 * 16 * D + 2 * 16 * DP;
     static constexpr size_t bytes = (size_t)n_real * 8 + (size_t)n_cplx * 16 + 16 * 8;
 };
 
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
     typedef LinLayout<D, DP, DIAG> L;
     constexpr int W = 2 * D, DD = D * D, N = DIAG ? D : DP;
     extern __shared__ double2 smem2[];
-    const int tid = threadIdx.x, r = tid & 15, grp = tid >> 4, rowbase = tid & 48;
+    const int tid = threadIdx.x, r = tid & 15, grp = tid >> 4;
     const bool do_step = (A.mode & 0xff) == 0;
     const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
 
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
     double *sPhi = ls;  ls += 16 * 4 * D;          // row a: Phi_qq[a][:], Phi_qp[a][:], Phi_pq[a][:], Phi_pp[a][:]
     double *svec = ls;  ls += 8 * 16;              // x0, g0, 1/m, st, 1/st
     cplx *sL1 = (cplx *)ls, *sL2 = sL1 + 16 * D;   // rows i < d' of L1, L2 (dense widths)
+    cplx *sR1 = sL2 + 16 * D, *sR2 = sR1 + 16 * DP; // rows b < D of R1, R2
     double *red = (double *)(sL1 + L::n_cplx);
 
     for (int e = tid; e < 16 * D; e += 256) {
@@ -54,6 +59,13 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
         if (!DIAG) {
             sL1[e] = i < DP ? ((const cplx *)A.hk.L1)[i * D + b] : c_make(0.0, 0.0);
             sL2[e] = i < DP ? ((const cplx *)A.hk.L2)[i * D + b] : c_make(0.0, 0.0);
+        }
+    }
+    if (!DIAG) {
+        for (int e = tid; e < 16 * DP; e += 256) {
+            const int i = e / DP, j = e - i * DP;
+            sR1[e] = i < D ? ((const cplx *)A.hk.R1)[i * DP + j] : c_make(0.0, 0.0);
+            sR2[e] = i < D ? ((const cplx *)A.hk.R2)[i * DP + j] : c_make(0.0, 0.0);
         }
     }
     for (int e = tid; e < 16 * 4 * D; e += 256) {
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
     }
     __syncthreads();
     const double x0 = svec[r], g0 = svec[16 + r], im = svec[32 + r], sta = svec[48 + r], ista = svec[64 + r];
-    kptr kR1 = (kptr)A.hk.R1, kR2 = (kptr)A.hk.R2, ksi = (kptr)A.hk.si;
+    kptr ksi = (kptr)A.hk.si;
 
     double esum = 0.0;
     const int64_t n = A.st.n, stride = (int64_t)gridDim.x * 16;
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
         const int64_t tr = active ? t0 + grp : n - 1;
         double *qp = A.st.qp + tr * 2 * D;
         double *M = A.st.mono + tr * 4 * (int64_t)DD;
-        asm volatile("" : "+s"(kR1), "+s"(kR2), "+s"(ksi));
+        asm volatile("" : "+s"(ksi));
         int lofs = 0;
         asm volatile("" : "+v"(lofs));
         const double *cH = sH + lofs, *cPhi = sPhi + lofs;
@@ -106,15 +118,20 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
         if (do_step) {
             // ---- (q, p, S): the explicit RK4 stages (V = E0 + g.dr + 1/2 dr.H.dr - origin, grad = g + H.dr) ----
             double qs = q, ps = p, kqs = 0.0, kps = 0.0, qn = 0.0, pn = 0.0, red5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-            sfor_bb<0, 4>([&](auto sc_) {
+            double hrow[D];
+#pragma unroll
+            for (int b = 0; b < D; ++b) hrow[b] = cH[r * D + b];
+            sfor<0, 4>([&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
                 if (s > 0) { const double c = (s == 3) ? dt : hh; qs = q + c * kqs; ps = p + c * kps; }
-                const double dr = r < D ? qs - x0 : 0.0;
-                double hd = 0.0;
+                double dr = r < D ? qs - x0 : 0.0;
+                double hd = 0.0, hd2 = 0.0;         // two chains: consecutive multiply-adds do not wait for each other
+                dpp_guard(dr);
                 sfor<0, D>([&](auto bc_) {
                     constexpr int b = decltype(bc_)::value;
-                    hd = fma(cH[r * D + b], bc<b>(dr), hd);
+                    if (b & 1) fmac_bc<b>(hd2, dr, hrow[b]); else fmac_bc<b>(hd, dr, hrow[b]);
                 });
+                hd += hd2;
                 const double v = dr * g0 + 0.5 * dr * hd;           // + scalar0 after the reduction
                 const double kq = ps * im, kp = -(g0 + hd), t = 0.5 * ps * ps * im;
                 red5[s] = t - v;
@@ -123,8 +140,20 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
                 qn += w * kq; pn += w * kp;
                 kqs = kq; kps = kp;
             });
+            {
+                double one = 1.0;
+                asm volatile("" : "+v"(one));
+                double s5[5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) red5[i] = row_sum(r < D ? red5[i] : 0.0);
+                for (int i = 0; i < 5; ++i) s5[i] = 0.0;
+                dpp_guard(red5);
+                sfor<0, D>([&](auto kc) {             // sums over the lanes k < D: fused broadcast multiply-adds with 1.0
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) fmac_bc<decltype(kc)::value>(s5[i], red5[i], one);
+                });
+#pragma unroll
+                for (int i = 0; i < 5; ++i) red5[i] = s5[i];
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) red5[s] -= A.pot.scalar0;
             red5[4] += A.pot.scalar0;
@@ -137,7 +166,7 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
             // ---- [X; Y] <- Phi [X; Y]: row g of the old blocks from lane g, Phi[r][g] from LDS.  Column c of the
             // result needs column c of the old blocks only: one half (Mqq, Mpq | Mqp, Mpp) at a time keeps the live
             // set at three quarter-matrices ----
-            sfor_bb<0, 2>([&](auto hc) {
+            sfor<0, 2>([&](auto hc) {
                 constexpr int c0 = decltype(hc)::value * D;
                 const double *Mq = M + (c0 ? DD : 0), *Mp = Mq + 2 * DD;
                 double Tq[D], Tp[D];
@@ -146,16 +175,16 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
                     Tq[b] = r < D ? Mq[r * D + b] : 0.0; Tp[b] = r < D ? Mp[r * D + b] : 0.0;
                     Xq[c0 + b] = 0.0; Xp[c0 + b] = 0.0;
                 }
-                sfor_bb<0, D>([&](auto gc) {
+                dpp_guard(Tq, Tp);
+                sfor<0, D>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
                     const double fqq = cPhi[r * 4 * D + g], fqp = cPhi[r * 4 * D + D + g];
                     const double fpq = cPhi[r * 4 * D + 2 * D + g], fpp = cPhi[r * 4 * D + 3 * D + g];
+                    // X[r][b] += Phi[r][g] * old[g][b]: the old row g comes from lane g inside the multiply-add
 #pragma unroll
-                    for (int b = 0; b < D; ++b) {
-                        const double xq = bc<g>(Tq[b]), xp = bc<g>(Tp[b]);
-                        Xq[c0 + b] = fma(fqq, xq, Xq[c0 + b]); Xq[c0 + b] = fma(fqp, xp, Xq[c0 + b]);
-                        Xp[c0 + b] = fma(fpq, xq, Xp[c0 + b]); Xp[c0 + b] = fma(fpp, xp, Xp[c0 + b]);
-                    }
+                    for (int b = 0; b < D; ++b) { fmac_bc<g>(Xq[c0 + b], Tq[b], fqq); fmac_bc<g>(Xp[c0 + b], Tq[b], fpq); }
+#pragma unroll
+                    for (int b = 0; b < D; ++b) { fmac_bc<g>(Xq[c0 + b], Tp[b], fqp); fmac_bc<g>(Xp[c0 + b], Tp[b], fpp); }
                 });
                 if (active && r < D) {
                     double *Oq = M + (c0 ? DD : 0), *Op = Oq + 2 * DD;
@@ -166,7 +195,7 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
         }
 
         // ---- prefactor matrix, row i of it in lane i ----
-        cplx mat[N], dummy[1] = {c_make(0.0, 0.0)};
+        cplx mat[N];
         if (DIAG) {
             // mat_ab = 1/2 [st_a/si_b Mqq + si_b/st_a Mpp - i hbar st_a si_b Mqp + i/hbar Mpq/(st_a si_b)]   (:969-986)
             WM_BLOCK {
@@ -182,39 +211,54 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
             // X1 = Mqq R1 - i hbar Mqp R2, X2 = Mpp R2 + i/hbar Mpq R1 (row r, in-lane with the uniform R1, R2);
             // mat' = 1/2 (L1 X1 + L2 X2): rows of X1, X2 from lane a, L1[i][a], L2[i][a] from LDS      (:969-994)
             cplx X1[DP], X2[DP];
-            sfor_bb<0, DP>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                cplx s1 = c_make(0, 0), s2 = c_make(0, 0), t1 = c_make(0, 0), t2 = c_make(0, 0);
+            {
+                // rows b of R1, R2 sit in lane b (LDS-staged per-lane rows); Xq, Xp are this lane's
+                cplx r1[DP], r2[DP];
+                cplx s1[DP], s2[DP], t1[DP], t2[DP];
 #pragma unroll
-                for (int b = 0; b < D; ++b) {
-                    const double r1x = kR1[2 * (b * DP + j)], r1y = kR1[2 * (b * DP + j) + 1];
-                    const double r2x = kR2[2 * (b * DP + j)], r2y = kR2[2 * (b * DP + j) + 1];
-                    s1.x = fma(Xq[b], r1x, s1.x); s1.y = fma(Xq[b], r1y, s1.y);
-                    s2.x = fma(Xq[D + b], r2x, s2.x); s2.y = fma(Xq[D + b], r2y, s2.y);
-                    t1.x = fma(Xp[D + b], r2x, t1.x); t1.y = fma(Xp[D + b], r2y, t1.y);
-                    t2.x = fma(Xp[b], r1x, t2.x); t2.y = fma(Xp[b], r1y, t2.y);
+                for (int j = 0; j < DP; ++j) {
+                    r1[j] = sR1[r * DP + j + lofs]; r2[j] = sR2[r * DP + j + lofs];
+                    s1[j] = c_make(0, 0); s2[j] = c_make(0, 0); t1[j] = c_make(0, 0); t2[j] = c_make(0, 0);
                 }
-                X1[j] = c_add(s1, c_mul(c_make(0.0, -SC_HBAR), s2));
-                X2[j] = c_add(t1, c_mul(c_make(0.0, 1.0 / SC_HBAR), t2));
-            });
+                dpp_guard(r1, r2);
+                sfor<0, D>([&](auto bcn) {
+                    constexpr int b = decltype(bcn)::value;
+#pragma unroll
+                    for (int j = 0; j < DP; ++j) {
+                        fmac_bc<b>(s1[j].x, r1[j].x, Xq[b]); fmac_bc<b>(s1[j].y, r1[j].y, Xq[b]);
+                        fmac_bc<b>(s2[j].x, r2[j].x, Xq[D + b]); fmac_bc<b>(s2[j].y, r2[j].y, Xq[D + b]);
+                        fmac_bc<b>(t1[j].x, r2[j].x, Xp[D + b]); fmac_bc<b>(t1[j].y, r2[j].y, Xp[D + b]);
+                        fmac_bc<b>(t2[j].x, r1[j].x, Xp[b]); fmac_bc<b>(t2[j].y, r1[j].y, Xp[b]);
+                    }
+                });
+#pragma unroll
+                for (int j = 0; j < DP; ++j) {
+                    X1[j] = c_add(s1[j], c_mul(c_make(0.0, -SC_HBAR), s2[j]));
+                    X2[j] = c_add(t1[j], c_mul(c_make(0.0, 1.0 / SC_HBAR), t2[j]));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < DP; ++j) mat[j] = c_make(0.0, 0.0);
-            sfor_bb<0, D>([&](auto ac) {
+            dpp_guard(X1, X2);
+            sfor<0, D>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
                 const cplx l1 = sL1[r * D + a + lofs], l2 = sL2[r * D + a + lofs];
 #pragma unroll
-                for (int j = 0; j < DP; ++j) {
-                    mat[j] = c_fma(l1, c_make(bc<a>(X1[j].x), bc<a>(X1[j].y)), mat[j]);
-                    mat[j] = c_fma(l2, c_make(bc<a>(X2[j].x), bc<a>(X2[j].y)), mat[j]);
-                }
+                for (int j = 0; j < DP; ++j) cfma_bc<a>(mat[j], X1[j], l1);
+#pragma unroll
+                for (int j = 0; j < DP; ++j) cfma_bc<a>(mat[j], X2[j], l2);
             });
 #pragma unroll
             for (int j = 0; j < DP; ++j) mat[j] = c_scale(mat[j], 0.5);
         }
-        int myk, src;
-        cplx det;
-        gauss_jordan_rows<N, 1>(mat, dummy, r >= N, r, rowbase, myk, src, det);
-        if (active && r == 0) {
+        // determinant in the fixed pivot order (sc_row16.h); a weak pivot hands the trajectory to the fully pivoted
+        // elimination of hk_step_kernel (fix-up launch of sc_hk_step, as on the separable fast path)
+        int weak = SC_LIN_FORCE_FIXUP;
+        const cplx det = det_rows_fixed_order<N>(mat, r, weak);
+        if (active && r == 0 && weak && A.st.flags) {
+            A.st.flags[tr] = 1;
+            atomicAdd(&A.st.flags[n], 1);
+        } else if (active && r == 0) {
             cplx *c2 = (cplx *)A.st.c2;
             if (do_step) {
                 const cplx prev = c2[tr];

@@ -5,16 +5,19 @@
 // to a multiple of four is a template parameter: every register index is static).  With a diagonal Hessian the RK4 step of
 // the monodromy rows is the 2 x 2 propagator P_a of the row (see sc_hk_step_sd.hip, hk_modes_kernel): the whole step is
 // lane-local, no cross-lane traffic at all.  Then the diagonal-width prefactor row (reference propagators.py:969-986),
-// the determinant by Gauss-Jordan elimination in which the pivot is a LANE (true partial pivoting, sc_row16.h) and the
-// branch tracker.  hk_step_w16_kernel spends a whole wavefront on a trajectory; at D = 5 that is 25 of 256 element slots.
+// the determinant by elimination in a FIXED pivot order -- the pivot row is a static lane, every update a fused broadcast
+// multiply-add (sc_row16.h: det_rows_fixed_order; round 2 searched the pivot lane and fetched its row with ds_bpermute) --
+// and the branch tracker.  A pivot more than 16 x below the best candidate flags the trajectory for the fully pivoted
+// fix-up launch of sc_hk_step (never for the diagonal monodromy blocks a separable potential produces from M(0) = 1).  hk_step_w16_kernel spends a whole wavefront on a trajectory; at D = 5 that is 25 of 256 element slots.
 // Workloads: BASELINE.json configs[0] (5 modes) and every separable / diagonal-width problem with D <= 12.
 #include "sc_common.h"
 #include "sc_row16.h"
 
-#ifndef SC_SEP16_MAX_D
-#define SC_SEP16_MAX_D 12    // 13 <= D <= 16 stay with hk_step_w16_kernel (measured at n = 1e5, step launch in ms, packed / one
-                             // wavefront per trajectory: D = 3: 0.07 / 0.24, 5: 0.12 / 0.29, 8: 0.18 / 0.35, 12: 0.37 / 0.50,
-                             // 14: 0.58 / 0.58, 16: 0.84 / 0.63)
+// SC_SEP16_MAX_D (sc_common.h) = 12: 13 <= D <= 16 stay with hk_step_w16_kernel (measured in round 2 at n = 1e5, step launch
+// in ms, packed / one wavefront per trajectory: D = 3: 0.07 / 0.24, 5: 0.12 / 0.29, 8: 0.18 / 0.35, 12: 0.37 / 0.50,
+// 14: 0.58 / 0.58, 16: 0.84 / 0.63)
+#ifndef SC_SEP16_FORCE_FIXUP
+#define SC_SEP16_FORCE_FIXUP 0   // 1: variant library that hands every determinant to the pivoted fix-up launch
 #endif
 
 namespace {
@@ -26,7 +29,7 @@ typedef unsigned int sc_v2u __attribute__((ext_vector_type(2)));
 template <int DP, bool STEP, int KIND>
 __global__ __launch_bounds__(256, 2) void hk_step_sep16_kernel(StepArgs A) {
     __shared__ double red[16];
-    const int D = A.st.dim, DD = D * D, tid = threadIdx.x, r = tid & 15, grp = tid >> 4, rowbase = tid & 48;
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x, r = tid & 15, grp = tid >> 4;
     const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
     const bool mine = r < D;
     const double sta = mine ? A.hk.st[r] : 1.0, ista = 1.0 / sta;
@@ -92,8 +95,17 @@ __global__ __launch_bounds__(256, 2) void hk_step_sep16_kernel(StepArgs A) {
                 rk4_pair(p11, p21, im, h1, h2, h3, h4, dt);       // (u, v) = (1, 0) -> first column of P_a
                 rk4_pair(p12, p22, im, h1, h2, h3, h4, dt);       // (0, 1) -> second column
             }
+            {
+                double one = 1.0, s5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+                asm volatile("" : "+v"(one));
+                dpp_guard(red5);
+                sfor<0, DP>([&](auto kc) {            // sums over the lanes k < DP (lanes beyond D hold zeros)
 #pragma unroll
-            for (int i = 0; i < 5; ++i) red5[i] = row_sum(red5[i]);
+                    for (int i = 0; i < 5; ++i) fmac_bc<decltype(kc)::value>(s5[i], red5[i], one);
+                });
+#pragma unroll
+                for (int i = 0; i < 5; ++i) red5[i] = s5[i];
+            }
             if (active && r == 0) {
                 A.st.act[tr] += h6 * (red5[0] + 2.0 * red5[1] + 2.0 * red5[2] + red5[3]);
                 esum += red5[4];
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void hk_step_sep16_kernel(StepArgs A) {
             }
         }
         // ---- prefactor row a (rows and columns beyond D: identity, lanes beyond DP: no row)
-        cplx mat[DP], dummy[1] = {c_make(0.0, 0.0)};
+        cplx mat[DP];
 #pragma unroll
         for (int b = 0; b < DP; ++b) {
             const double sib = b < D ? ksi[b] : 1.0, isib = 1.0 / sib;
@@ -117,10 +129,12 @@ __global__ __launch_bounds__(256, 2) void hk_step_sep16_kernel(StepArgs A) {
                                               0.5 * (-SC_HBAR * sta * sib * mqp[b] + (1.0 / SC_HBAR) * ista * isib * mpq[b]))
                                      : c_make(r == b ? 1.0 : 0.0, 0.0);
         }
-        int myk, src;
-        cplx det;
-        gauss_jordan_rows<DP, 1>(mat, dummy, r >= DP, r, rowbase, myk, src, det);
-        if (active && r == 0) {
+        int weak = SC_SEP16_FORCE_FIXUP;
+        const cplx det = det_rows_fixed_order<DP>(mat, r, weak);
+        if (active && r == 0 && weak && A.st.flags) {
+            A.st.flags[tr] = 1;                       // c2 / sgn are left to the fully pivoted fix-up launch
+            atomicAdd(&A.st.flags[n], 1);
+        } else if (active && r == 0) {
             cplx *c2 = (cplx *)A.st.c2;
             if (STEP) {
                 const cplx prev = c2[tr];

@@ -195,6 +195,34 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// |pivot|^2 more than 2^8 below the largest candidate partial pivoting could have taken: the fixed pivot order is not
+// good enough for this matrix (the caller hands the trajectory to a fully pivoted kernel)
+__device__ __forceinline__ bool weak_pivot_keys(int key_pivot, int key_max) { return key_max - key_pivot > (8 << 20); }
+
+// det of the N x N complex matrix held one ROW per lane (lane i: m[0..N); rows >= N must be zero), by Gaussian elimination
+// in the FIXED pivot order 0 .. N-1: the pivot row is a static lane, every update is a fused broadcast multiply-add
+// (cfnma_inplace), nothing goes through LDS.  `weak` is set (in every lane of the row) if a pivot is zero or more than a
+// factor 16 below the largest entry of its column among the rows still to be eliminated.  m is destroyed.
+template <int N>
+__device__ __forceinline__ cplx det_rows_fixed_order(cplx (&m)[N], int r, int &weak) {
+    cplx det = c_make(1.0, 0.0);
+    sfor<0, N>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int key = (r >= k && r < N) ? __double2hiint(c_abs2(m[k])) : 0;
+        const int key_max = row_max(key), key_piv = bc_i32<k>(key);
+        if (weak_pivot_keys(key_piv, key_max) || key_piv == 0) weak = 1;
+        const cplx piv = c_make(bc<k>(m[k].x), bc<k>(m[k].y));
+        det = c_mul(det, piv);
+        if constexpr (k + 1 < N) {
+            const cplx f = c_mul(m[k], c_inv_newton(piv));
+            const cplx mult = c_make(r > k ? f.x : 0.0, r > k ? f.y : 0.0);      // rows <= k (the pivot lane among them) stay
+            dpp_guard(m);
+            cfnma_inplace_range<k, k + 1, N>(m, mult);
+        }
+    });
+    return det;
+}
+
 // Gauss-Jordan elimination of the N x N complex system held one ROW per lane (lane i: a[0..N) and NR right-hand
 // sides b[0..NR)); rows >= N must be zero and enter with used = true.  Partial pivoting over the unused LANES for
 // column k.  Rows are not normalised while eliminating: a lane subtracts m = a_ik / pivot times the pivot row, the

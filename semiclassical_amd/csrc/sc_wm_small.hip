@@ -80,8 +80,6 @@ __device__ __forceinline__ void sum_rows(cplx (&t)[M], const double &one) {
     for (int m = 0; m < M; ++m) t[m] = c_make(s[2 * m], s[2 * m + 1]);
 }
 
-// |pivot|^2 more than 2^8 below the largest candidate: hand the trajectory to the pivoted kernel
-__device__ __forceinline__ bool weak_keys(int key_pivot, int key_max) { return key_max - key_pivot > (8 << 20); }
 
 template <int D, int DP>
 __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A) {
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             int key_max = 0;
             sfor<k + 1, E>([&](auto ic) { key_max = max(key_max, __double2hiint(c_abs2(rowA[decltype(ic)::value]))); });
             const double mag = c_abs2(rowA[k]);
-            if (r == k && (weak_keys(__double2hiint(mag), key_max) || mag == 0.0)) weak = 1;
+            if (r == k && (weak_pivot_keys(__double2hiint(mag), key_max) || mag == 0.0)) weak = 1;
             const cplx piv = c_make(bc<k>(rowA[k].x), bc<k>(rowA[k].y));
             detA = c_mul(detA, piv);
             const cplx inv = c_inv_newton(piv);
@@ -418,7 +416,7 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
             const double mag = c_abs2(ms[k]);
             const int key = (r >= k && r < DP) ? __double2hiint(mag) : 0;
             const int key_max = row_max(key), key_piv = bc_i32<k>(key);
-            if (weak_keys(key_piv, key_max) || key_piv == 0) weak = 1;      // (a zero or denormal pivot goes to the pivoted kernel)
+            if (weak_pivot_keys(key_piv, key_max) || key_piv == 0) weak = 1;      // (a zero or denormal pivot goes to the pivoted kernel)
             const cplx piv = c_make(bc<k>(ms[k].x), bc<k>(ms[k].y));
             detM = c_mul(detM, piv);
             const cplx inv = c_inv_newton(piv);
