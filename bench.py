@@ -305,6 +305,9 @@ def parse_args(argv=None):
                     help="trajectories of the whole job, sharded over the GPUs (default at --gpus 8: 10^6 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration lines and the 2000-step run")
+    ap.add_argument("--config", choices=["1", "3", "5"], default=None,
+                    help="run ONLY that BASELINE configuration's side measurement (for one rocprofv3 summary per configuration: "
+                         "1 = 5-mode AS at n = 1e5, 3 = methylium WM at n = 1e5, 5 = 30-atom sGDML at n = 1e4) and print its JSON")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -320,6 +323,11 @@ def main():
         return launch_check()
 
     torch.set_default_dtype(torch.float64)
+    if args.config is not None:
+        dev = torch.device("cuda", 0)
+        fn, fargs = {"1": (config1, (100000, 50)), "3": (config3, (100000, 30)), "5": (config5, (10000, 3))}[args.config]
+        print(json.dumps({f"config{args.config}": fn(dev, *fargs)}), flush=True)
+        return
     from semiclassical_amd import distributed as D
     rank, world, local = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

@@ -261,11 +261,17 @@ __global__ __launch_bounds__(64 * NT, 1) void dense_mono_mfma_big_kernel(MonoArg
 // written once (2 x 4 D^2 x 8 B) and the four stage Hessians are read once per slab (2 NT / 4 slabs), against ~3 MB
 // through the global scratch of dense_mono_mfma_big_kernel.  One Hessian image in LDS (rows padded to 112 doubles); the
 // next stage's image is fetched into registers behind the current stage's MFMAs.
-template <int NT, int KT>
-__global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A) {
+// DMA (round 3): the stage Hessians go from L2 / HBM straight into the LDS image with 16-byte LDS-DMA loads
+// (global_load_lds_dwordx4: no registers, no index arithmetic per element -- the register path spent ~2400 instructions per
+// stage, divisions by D among them, behind the 138 MFMAs of a stage, and the matrix pipe sat idle for two thirds of the
+// launch).  A wave instruction fills 1 KB of the image's linear space; the lanes that fall on the padding columns are
+// switched off, so padding rows and columns keep the zeros they were given at kernel start.  Needs 16-byte aligned rows
+// (D even); odd D keeps the register path.
+template <int NT, int KT, bool DMA>
+__device__ __forceinline__ void dense_mono_mfma_slab_body(const MonoArgs &A) {
     extern __shared__ double2 smem2[];           // Hessian image [16 NT][HSB], 1/m [128]
     constexpr int HB = 16 * NT * HSB, NSLAB = (2 * NT + 3) / 4;
-    constexpr int HPT = (16 * NT * 16 * NT + 255) / 256;      // Hessian elements fetched per thread
+    constexpr int HPT = (16 * NT * 16 * NT + 255) / 256;      // Hessian elements fetched per thread (register path)
     double *Hs0 = (double *)smem2, *wm = Hs0 + HB;
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, rg = lane >> 4;
@@ -273,6 +279,17 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A
     for (int i = tid; i < 128; i += 256) wm[i] = i < D ? A.inv_mass[i] : 0.0;
     for (int e = tid; e < HB; e += 256) Hs0[e] = 0.0;                        // padding rows / columns stay zero
     __syncthreads();
+    // image rows 0 .. D-1 in 16-byte units: unit u = row * (HSB / 2) + cu holds columns 2 cu, 2 cu + 1
+    auto fetch_image = [&](const double *src) {
+        constexpr int UPR = HSB / 2;
+        const int upd = D >> 1, total = D * UPR;
+        for (int u0 = 64 * __builtin_amdgcn_readfirstlane(wave); u0 < total; u0 += 256) {
+            const int u = u0 + lane, row = u / UPR, cu = u - row * UPR;
+            if (u < total && cu < upd)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)row * D + 2 * cu),
+                                                 (__attribute__((address_space(3))) void *)(Hs0 + 2 * u0), 16, 0, 0);
+        }
+    };
     const int64_t items = A.st.n * NSLAB;
     for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
         const int64_t tr = item / NSLAB;
@@ -285,7 +302,8 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A
         double *Mx = A.st.mono + tr * 4 * (int64_t)DD + (int64_t)pair * DD, *My = Mx + 2 * (int64_t)DD;
         const double *Hg = A.hess + tr * A.hess_stride;
         __syncthreads();                                                     // the previous item's last image is done with
-        for (int e = tid; e < DD; e += 256) Hs0[(e / D) * HSB + (e % D)] = Hg[e];
+        if (DMA) fetch_image(Hg);
+        else for (int e = tid; e < DD; e += 256) Hs0[(e / D) * HSB + (e % D)] = Hg[e];
         double SX[NT][4], SY[NT][4], Xs[NT][4], Ys[NT][4], X0[NT][4], Y0[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -298,14 +316,15 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A
             }
 #pragma unroll 1
         for (int st = 0; st < 4; ++st) {
+            if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): this wavefront's part of the image has landed
             __syncthreads();                                                 // image of this stage complete
-            double hn[HPT];
+            double hn[DMA ? 1 : HPT];
             const double *Hn = Hg + (st + 1) * A.stage_stride;
-            if (st < 3) {
+            if (!DMA && st < 3) {
 #pragma unroll
                 for (int i = 0; i < HPT; ++i) {
                     const int e = tid + i * 256;
-                    hn[i] = e < DD ? Hn[e] : 0.0;
+                    hn[DMA ? 0 : i] = e < DD ? Hn[e] : 0.0;
                 }
             }
             d4 acc[NT];
@@ -330,6 +349,10 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A
 #pragma unroll
                 for (int I = 0; I < NT; ++I) a_cur[I] = a_nxt[I];
             }
+            if (DMA && st < 3) {
+                __syncthreads();                                             // everybody has read this stage's image:
+                fetch_image(Hn);                                             // the next one streams in under the update below
+            }
             const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -340,12 +363,12 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A
                     Xs[t][r] = fma(c, kx, X0[t][r]);
                     Ys[t][r] = fma(c, ky, Y0[t][r]);
                 }
-            if (st < 3) {
+            if (!DMA && st < 3) {
                 __syncthreads();                                             // everybody has read this stage's image
 #pragma unroll
                 for (int i = 0; i < HPT; ++i) {
                     const int e = tid + i * 256;
-                    if (e < DD) Hs0[(e / D) * HSB + (e % D)] = hn[i];
+                    if (e < DD) Hs0[(e / D) * HSB + (e % D)] = hn[DMA ? 0 : i];
                 }
             }
         }
@@ -360,6 +383,170 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_kernel(MonoArgs A
             }
     }
 }
+
+// TWO images (D <= 90: (2 D + 2) rows of 112 doubles fit the 160 KB), stages as ONE stream across the slabs a workgroup
+// processes: while the products of stage g run on image g & 1, the Hessian of stage g + 1 -- the next stage of this slab or
+// stage 0 of the workgroup's next slab -- is requested into the other image, two LDS-DMA loads per k-slice, from offsets
+// computed once per kernel.  Their issue slots lie in the shadow of the MFMAs (a k-slice keeps the matrix pipe busy for
+// ~400 cycles and needs three LDS reads), they have more than half a stage to land, and a stage needs ONE barrier: with
+// one image the request went out behind the products, cost ~25 instructions per load in the open and its HBM round trip
+// (the 2.6 GB of stage Hessians of a batch stay in no cache) lay bare in front of the next stage.
+// The images are packed (image 1 starts at row D): the k-slice that reaches beyond row D - 1 reads rows of the other image /
+// of a zeroed tail, multiplied by rows of the stage matrix that are exactly zero.  1/m lives in registers.
+// hipcc must not know that the A operands are LDS reads: behind an LDS-DMA it puts `s_waitcnt vmcnt(0)` in front of every
+// LDS read that may alias the DMA's destination -- and in front of every __syncthreads() (a workgroup release fence).  So
+// the operand reads are inline-assembly ds_read2_b64 with their own lgkmcnt waits, and the barrier inside the loop is a
+// bare s_barrier behind an explicit wait.
+typedef double sc_d2v __attribute__((ext_vector_type(2)));
+// A operands of one k-slice: doubles 0, 16, 32, ... (16 (NT-1)) behind byte address `addr` of the LDS image, as NT/2
+// ds_read2_b64 (offsets in units of 8 bytes) the compiler does not see as LDS reads
+template <int NT>
+__device__ __forceinline__ void lds_a_operands(unsigned addr, sc_d2v (&a)[3]) {
+    static_assert(NT == 5 || NT == 6, "slab kernels: 64 < D <= 96");
+    if constexpr (NT == 6)
+        asm volatile("ds_read2_b64 %0, %3 offset1:16\n\tds_read2_b64 %1, %3 offset0:32 offset1:48\n\tds_read2_b64 %2, %3 offset0:64 offset1:80"
+                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]) : "v"(addr));
+    else
+        asm volatile("ds_read2_b64 %0, %3 offset1:16\n\tds_read2_b64 %1, %3 offset0:32 offset1:48\n\tds_read2_b64 %2, %3 offset0:64 offset1:64"
+                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]) : "v"(addr));
+}
+// wait until at most the LDS reads of ONE k-slice (three instructions) are outstanding; the operands pass through the
+// statement so that their consumers are ordered behind it
+__device__ __forceinline__ void lds_a_wait_previous(sc_d2v (&a)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
+}
+__device__ __forceinline__ void lds_a_wait_all(sc_d2v (&a)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
+}
+
+template <int NT, int KT>
+__global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) {
+    extern __shared__ double2 smem2[];           // Hessian images [2 D + 2][HSB]
+    constexpr int NSLAB = (2 * NT + 3) / 4, UPR = HSB / 2;
+    constexpr int NDMA = (16 * NT * UPR + 255) / 256;          // LDS-DMA instructions per image and wavefront
+    static_assert(2 * KT >= NDMA + 2, "two requests per k-slice have to fit into a stage's product loop");
+    double *Hs0 = (double *)smem2;
+    const int D = A.st.dim, DD = D * D, tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), rg = lane >> 4;
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    for (int e = tid; e < (2 * D + 2) * HSB; e += 256) Hs0[e] = 0.0;        // padding columns and the tail rows stay zero
+    double wmr[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wmr[t][r] = 16 * t + rg + 4 * r < D ? A.inv_mass[16 * t + rg + 4 * r] : 0.0;
+    // image rows 0 .. D-1 in 16-byte units: unit u = row * UPR + cu holds columns 2 cu, 2 cu + 1.  Request j of a wavefront
+    // covers the 64 units from u0_j = min(64 wave + 256 j, total - 64) (the last requests re-cover the image's tail, so that
+    // every wavefront issues exactly NDMA of them); lanes on padding columns are switched off (offset -1).
+    const int upd = D >> 1, total = D * UPR;
+    int soff[NDMA];                                                         // byte offset of this lane's unit inside a D x D Hessian
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+        const int u = min(64 * wave + 256 * j, total - 64) + lane, row = u / UPR, cu = u - row * UPR;
+        soff[j] = cu < upd ? 8 * (row * D + 2 * cu) : -1;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)Hs0;
+    __syncthreads();
+    auto request = [&](const double *src, int buf, int j) {                 // request j of the image of `src` into image `buf`
+        const int u0 = min(64 * wave + 256 * j, total - 64);
+        if (soff[j] >= 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)src + (unsigned)soff[j]),
+                                             (__attribute__((address_space(3))) void *)(Hs0 + (size_t)buf * D * HSB + 2 * u0), 16, 0, 0);
+    };
+    const int64_t items = A.st.n * NSLAB;
+    if ((int64_t)blockIdx.x < items) {
+        const double *H0 = A.hess + ((int64_t)blockIdx.x / NSLAB) * A.hess_stride;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) request(H0, 0, j);                   // stage 0 of the first slab (the only unhidden image)
+    }
+    int g = 0;                                                               // stages this workgroup has started: image g & 1
+    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const int64_t tr = item / NSLAB;
+        const int ct = 4 * (int)(item - tr * NSLAB) + wave;                  // column tile of [X | X'] this wavefront owns
+        const bool active = ct < 2 * NT;
+        const int pair = active ? ct / NT : 0, jt = active ? ct % NT : 0;    // pair 0: (Mqq, Mpq), pair 1: (Mqp, Mpp)
+        const int col = 16 * jt + (lane & 15);
+        const bool colok = active && col < D;
+        const unsigned toff = (unsigned)(rg * D + col);
+        double *Mx = A.st.mono + tr * 4 * (int64_t)DD + (int64_t)pair * DD, *My = Mx + 2 * (int64_t)DD;
+        const double *Hg = A.hess + tr * A.hess_stride;
+        const int64_t nitem = item + gridDim.x;
+        const double *Hnext_item = nitem < items ? A.hess + (nitem / NSLAB) * A.hess_stride : nullptr;
+        double SX[NT][4], SY[NT][4], Xs[NT][4], Ys[NT][4], X0[NT][4], Y0[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = colok && 16 * t + rg + 4 * r < D;
+                X0[t][r] = Xs[t][r] = ok ? (Mx + (16 * t + 4 * r) * D)[toff] : 0.0;
+                Y0[t][r] = Ys[t][r] = ok ? (My + (16 * t + 4 * r) * D)[toff] : 0.0;
+                SX[t][r] = 0.0; SY[t][r] = 0.0;
+            }
+#pragma unroll 1
+        for (int st = 0; st < 4; ++st, ++g) {
+            // the image of this stage was requested during the previous stage's products: this wavefront's part has landed ...
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            // ... and everybody's; also: every wavefront is through the products of the previous stage, whose image the
+            // requests below overwrite
+            __builtin_amdgcn_s_barrier();
+            const double *Hnext = st < 3 ? Hg + (st + 1) * A.stage_stride : Hnext_item;
+            const int nbuf = (g + 1) & 1;
+            d4 acc[NT];
+#pragma unroll
+            for (int I = 0; I < NT; ++I) acc[I] = (d4){0.0, 0.0, 0.0, 0.0};
+            // byte address of this lane's first A operand in the image of this stage; + 4 rows per k-slice
+            unsigned aaddr = lds_base + 8u * (unsigned)((g & 1) * D * HSB + rg * HSB + (lane & 15));
+            sc_d2v a_cur[3], a_nxt[3];
+            lds_a_operands<NT>(aaddr, a_cur);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt + 1 < KT) {
+                    aaddr += 8u * 4u * HSB;
+                    lds_a_operands<NT>(aaddr, a_nxt);
+                    lds_a_wait_previous(a_cur);
+                } else {
+                    lds_a_wait_all(a_cur);
+                }
+                const double b = Xs[kt >> 2][kt & 3];
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[I >> 1][I & 1], b, acc[I], 0, 0, 0);
+                // two requests of the next stage's image in the shadow of this k-slice's MFMAs
+                if (Hnext) {
+                    if (2 * kt < NDMA) request(Hnext, nbuf, 2 * kt);
+                    if (2 * kt + 1 < NDMA) request(Hnext, nbuf, 2 * kt + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) a_cur[i] = a_nxt[i];
+            }
+            const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double kx = wmr[t][r] * Ys[t][r], ky = -acc[t][r];
+                    SX[t][r] = fma(wgt, kx, SX[t][r]); SY[t][r] = fma(wgt, ky, SY[t][r]);
+                    Xs[t][r] = fma(c, kx, X0[t][r]);
+                    Ys[t][r] = fma(c, ky, Y0[t][r]);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (colok && 16 * t + rg + 4 * r < D) {
+                    (Mx + (16 * t + 4 * r) * D)[toff] = fma(h6, SX[t][r], X0[t][r]);
+                    (My + (16 * t + 4 * r) * D)[toff] = fma(h6, SY[t][r], Y0[t][r]);
+                }
+            }
+    }
+}
+
+template <int NT, int KT>
+__global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma(MonoArgs A) { dense_mono_mfma_slab_body<NT, KT, true>(A); }
+template <int NT, int KT>
+__global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_reg(MonoArgs A) { dense_mono_mfma_slab_body<NT, KT, false>(A); }
 
 // prefactor matrix, determinant and branch tracker from the monodromy blocks in global memory
 __global__ __launch_bounds__(256) void dense_prefactor_kernel(MonoArgs A) {
@@ -611,6 +798,29 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
             hipLaunchKernelGGL((KERNEL_<NT_, KT_>), dim3((unsigned)(items_ < g_ ? items_ : g_)),                    \
                                dim3(THREADS_), rk4_lds, s, a);                                                      \
         } while (0)
+        // slab kernel: Hessian images by LDS-DMA when the rows are 16-byte aligned (D even, 16-byte aligned base and strides)
+        const bool dma_ok = (D % 2 == 0) && (((uintptr_t)hess & 15) == 0);
+        const size_t lds2 = (size_t)(2 * D + 2) * HSB * sizeof(double);      // two packed images (dense_mono_mfma_slab_dma2)
+        const bool two_images = lds2 <= 160 * 1024;
+#define SC_LAUNCH_SLAB(NT_, KT_)                                                                                    \
+        do {                                                                                                        \
+            if (dma_ok && two_images) {                                                                             \
+                const size_t keep_ = rk4_lds;                                                                       \
+                (void)keep_;                                                                                        \
+                if (hipFuncSetAttribute((const void *)dense_mono_mfma_slab_dma2<NT_, KT_>,                          \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)       \
+                    return sc_check_launch("sc_dense_mono_step (LDS attribute)");                                   \
+                const int64_t g_ = (int64_t)cus * 4, items_ = st->n * ((2 * nt + 3) / 4);                           \
+                hipLaunchKernelGGL((dense_mono_mfma_slab_dma2<NT_, KT_>), dim3((unsigned)(items_ < g_ ? items_ : g_)), \
+                                   dim3(256), lds2, s, a);                                                          \
+            } else if (dma_ok) SC_LAUNCH_MONO(dense_mono_mfma_slab_dma, NT_, KT_, 4, 256);                          \
+            else SC_LAUNCH_MONO(dense_mono_mfma_slab_reg, NT_, KT_, 4, 256);                                        \
+        } while (0)
+#define SC_SLAB_CASES(NT_)                                                                                          \
+        case 4 * NT_ - 3: SC_LAUNCH_SLAB(NT_, 4 * NT_ - 3); break;                                                  \
+        case 4 * NT_ - 2: SC_LAUNCH_SLAB(NT_, 4 * NT_ - 2); break;                                                  \
+        case 4 * NT_ - 1: SC_LAUNCH_SLAB(NT_, 4 * NT_ - 1); break;                                                  \
+        case 4 * NT_: SC_LAUNCH_SLAB(NT_, 4 * NT_); break;
 #define SC_MONO_CASES(KERNEL_, NT_, WGS_, THREADS_)                                                                 \
         case 4 * NT_ - 3: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_ - 3, WGS_, THREADS_); break;                         \
         case 4 * NT_ - 2: SC_LAUNCH_MONO(KERNEL_, NT_, 4 * NT_ - 2, WGS_, THREADS_); break;                         \
@@ -627,11 +837,13 @@ extern "C" int sc_dense_mono_step(const sc_state *st, const sc_hk_consts *hk, co
                 SC_MONO_CASES(dense_mono_mfma_kernel, 2, 4, 256)
                 SC_MONO_CASES(dense_mono_mfma_kernel, 3, 1, 384)
                 SC_MONO_CASES(dense_mono_mfma_kernel, 4, 1, 512)
-                SC_MONO_CASES(dense_mono_mfma_slab_kernel, 5, 4, 256)
-                SC_MONO_CASES(dense_mono_mfma_slab_kernel, 6, 4, 256)
+                SC_SLAB_CASES(5)
+                SC_SLAB_CASES(6)
             }
         }
 #undef SC_MONO_CASES
+#undef SC_SLAB_CASES
+#undef SC_LAUNCH_SLAB
 #undef SC_LAUNCH_MONO
         const int rc = sc_check_launch("sc_dense_mono_step (RK4)");
         if (rc) return rc;
