@@ -61,7 +61,7 @@ def wm_flops_per_traj_step(D, dp):
 
 def profiled_traffic(n, dim):
     """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/), if they match this workload"""
-    for name in ("r2_hbm_traffic.json", "r1_hbm_traffic.json"):
+    for name in ("r3_hbm_traffic.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)

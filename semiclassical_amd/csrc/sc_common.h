@@ -138,6 +138,7 @@ struct StepArgs {
     double dt;
     int mode;
     double *epart;
+    int npart;          // entries of epart the energy guard adds up (sc_step_grid); kernels with fewer workgroups clear the rest
 };
 
 // V, dV/dx, d2V/dx2 of one mode of a separable potential

@@ -269,7 +269,7 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     dbg = getenv("SC_DEBUG_SKIP_LU") ? 0x100 : 0;      // the fix-up launch is skipped (the ablated kernel is a variant library, SC_SD_ABLATE_LU)
 #endif
     if (fast) {
-        StepArgs a{*pot, *st, *hk, dt, mode | dbg, energy_partials};
+        StepArgs a{*pot, *st, *hk, dt, mode | dbg, energy_partials, sc_step_grid(st->n, st->dim)};
 #ifdef SC_TUNING
         // SC_FAST_KERNEL=rw: the rejected row-wave layout of tools/variants/sc_hk_step_rw.hip
         const char *which = getenv("SC_FAST_KERNEL");
@@ -293,7 +293,7 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     if (dense) doubles += 7 * 2 * DD + DD + D;
     const size_t lds = doubles * sizeof(double) + 16;
     if (lds > 160 * 1024) return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_step: needs %zu B of LDS (D=%d)", lds, D);
-    StepArgs a{*pot, *st, *hk, dt, mode, energy_partials};
+    StepArgs a{*pot, *st, *hk, dt, mode, energy_partials, sc_step_grid(st->n, st->dim)};
     const int threads = step_threads(D), grid = sc_step_grid(st->n, D);
     hipStream_t s = (hipStream_t)stream;
     // constant Hessian, D <= 16 and the step matrix Phi(dt) at hand: the register kernel of sc_hk_step_lin.hip

@@ -110,7 +110,7 @@ extern "C" int sc_hk_step_diag(const sc_potential *pot, const sc_state *st, cons
     if (pot->kind != SC_POT_MORSE && pot->kind != SC_POT_HARMONIC_SEP && pot->kind != SC_POT_EPS_MORSE)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step_diag: potential kind %d is not separable", pot->kind);
     if (st->n <= 0) return SC_OK;
-    StepArgs a{*pot, *st, *hk, dt, mode, energy_partials};
+    StepArgs a{*pot, *st, *hk, dt, mode, energy_partials, sc_step_grid(st->n, st->dim)};
     const int grid = sc_step_grid(st->n, D);
     if ((mode & 0xff) == 0) hipLaunchKernelGGL(hk_diag_step_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, mono_diag);
     else hipLaunchKernelGGL(hk_diag_step_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, mono_diag);

@@ -166,15 +166,21 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
             // ---- [X; Y] <- Phi [X; Y]: row g of the old blocks from lane g, Phi[r][g] from LDS.  Column c of the
             // result needs column c of the old blocks only: one half (Mqq, Mpq | Mqp, Mpp) at a time keeps the live
             // set at three quarter-matrices ----
-            sfor<0, 2>([&](auto hc) {
-                constexpr int c0 = decltype(hc)::value * D;
-                const double *Mq = M + (c0 ? DD : 0), *Mp = Mq + 2 * DD;
-                double Tq[D], Tp[D];
+            // the step's old rows [Mqq | Mqp], [Mpq | Mpp]: BOTH halves requested together -- one HBM round trip per trajectory
+            // instead of one per half of the product (the kernel waits for memory 60 % of its time, profiles/r3_wm_pmc.json)
+            double Told[2][2][D];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int b = 0; b < D; ++b) {
-                    Tq[b] = r < D ? Mq[r * D + b] : 0.0; Tp[b] = r < D ? Mp[r * D + b] : 0.0;
-                    Xq[c0 + b] = 0.0; Xp[c0 + b] = 0.0;
+                    Told[h][0][b] = r < D ? M[(h ? DD : 0) + r * D + b] : 0.0;
+                    Told[h][1][b] = r < D ? M[(h ? DD : 0) + 2 * DD + r * D + b] : 0.0;
                 }
+            sfor<0, 2>([&](auto hc) {
+                constexpr int c0 = decltype(hc)::value * D;
+                double (&Tq)[D] = Told[decltype(hc)::value][0], (&Tp)[D] = Told[decltype(hc)::value][1];
+#pragma unroll
+                for (int b = 0; b < D; ++b) { Xq[c0 + b] = 0.0; Xp[c0 + b] = 0.0; }
                 dpp_guard(Tq, Tp);
                 sfor<0, D>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
@@ -276,6 +282,9 @@ __global__ __launch_bounds__(256, SC_LIN_OCC) void hk_step_lin_kernel(StepArgs A
         for (int g = 0; g < 16; ++g) s += red[g];
         A.epart[blockIdx.x] = s;
     }
+    // the energy guard adds sc_step_grid(n, D) partials: workgroup 0 zeroes the ones no workgroup owns
+    if (blockIdx.x == 0 && A.epart && do_step)
+        for (int i = gridDim.x + tid; i < A.npart; i += 256) A.epart[i] = 0.0;
 }
 
 template <int D, int DP, bool DIAG>
@@ -284,7 +293,10 @@ int launch(const StepArgs &a, int grid, hipStream_t s) {
     if (hipFuncSetAttribute((const void *)hk_step_lin_kernel<D, DP, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
         return sc_check_launch("sc_hk_step (LDS attribute)");
-    hipLaunchKernelGGL((hk_step_lin_kernel<D, DP, DIAG>), dim3(grid), dim3(256), lds, s, a);
+    // persistent grid: two workgroups per CU are resident (256 registers per lane); every further workgroup would stage the
+    // constants (12 KB) again for one or two passes over 16 trajectories.  The kernel clears the energy partials it leaves.
+    const int resident = 2 * 256;
+    hipLaunchKernelGGL((hk_step_lin_kernel<D, DP, DIAG>), dim3(grid < resident ? grid : resident), dim3(256), lds, s, a);
     const int rc = sc_check_launch("sc_hk_step (constant-Hessian register kernel)");
     return rc == SC_OK ? 1 : rc;
 }

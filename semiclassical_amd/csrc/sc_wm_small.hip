@@ -536,7 +536,9 @@ int launch(const WmArgs &a, int grid, hipStream_t s) {
     if (hipFuncSetAttribute((const void *)wm_small_kernel<D, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
         return sc_check_launch("sc_wm_correlate (LDS attribute)");
-    hipLaunchKernelGGL((wm_small_kernel<D, DP>), dim3(grid), dim3(256), lds, s, a);
+    // persistent grid: two workgroups per CU are resident; every further one would stage the constants (16 KB) again
+    const int resident = 2 * 256;
+    hipLaunchKernelGGL((wm_small_kernel<D, DP>), dim3(grid < resident ? grid : resident), dim3(256), lds, s, a);
     int rc = sc_check_launch("sc_wm_correlate (register-resident kernel)");
     if (rc != SC_OK) return rc;
     hipLaunchKernelGGL(wm_tail_kernel, dim3(grid), dim3(256), 0, s, a);        // partials[0 .. grid)

@@ -5,11 +5,13 @@
 
 Every pass directory holds one rocpd database (rocprofv3 --kernel-trace --pmc <counters> -d DIR ...).  For each kernel whose
 name contains one of the substrings: launches, the mean of every counter per launch, and the derived figures
-    valu_busy      = SQ_ACTIVE_INST_VALU * 4 / SQ_WAVE_CYCLES      (wave-cycles in which the wave had a VALU instruction in flight)
-    wait_fraction  = SQ_WAIT_ANY / SQ_WAVE_CYCLES                  (wave parked at s_waitcnt / barrier)
-    issue_stall    = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
-    waves_per_simd = SQ_WAVE_CYCLES / (SQ_BUSY_CYCLES * SIMDs)     (mean resident waves while the SQ was busy)
+    valu_busy      = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES   fraction of a wave's resident time with a VALU instruction executing
+    active         = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES    ... with any instruction executing
+    wait_fraction  = SQ_WAIT_ANY / SQ_WAVE_CYCLES           ... parked at s_waitcnt / barrier
+    issue_stall    = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES      ... waiting to issue (dependency, pipe busy)
+                     (active + wait + issue_stall ~ 1: the three are disjoint, MI355X_MICROARCH.md "rocprofv3 PMC slots")
     lds_conflict   = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  All are PER-WAVE fractions: with w waves resident per SIMD the SIMD's VALU is busy ~ w * valu_busy of the time.
 as far as the counters were collected (missing ones give null).  Counter semantics: MI355X_MICROARCH.md, rocprofv3 PMC slots.
 """
 import glob
@@ -47,14 +49,14 @@ def main():
         res["kernels"][short] = {
             "launches": max(len(v) for v in cs.values()),
             "counters_mean_per_launch": mean,
-            "valu_busy": ratio("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", 4.0),
+            "valu_busy": ratio("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"),
             "wait_fraction": ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"),
             "issue_stall_fraction": ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"),
-            "active_fraction": ratio("SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", 4.0),
+            "active_fraction": ratio("SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"),
             "lds_conflict_fraction": ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
             "valu_insts_per_wave": ratio("SQ_INSTS_VALU", "SQ_WAVES"),
             "lds_insts_per_wave": ratio("SQ_INSTS_LDS", "SQ_WAVES"),
-            "mean_waves_in_flight_per_simd": ratio("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", 1.0 / 4.0) if g("SQ_BUSY_CYCLES") else None,
+            "wave_cycles_per_busy_cycle": ratio("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"),
         }
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)

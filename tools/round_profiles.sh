@@ -1,0 +1,20 @@
+#!/bin/bash
+# Everything under profiles/ for one round, in one session on the GPU box:  tools/round_profiles.sh r3
+set -e
+cd "$(dirname "$0")/.."
+tag=${1:-r3}
+export TMPDIR=/tmp
+out=gpurun_out/prof_$tag
+dst=gpurun_out/profiles_$tag       # summaries (small): gpurun merges gpurun_out/ back, copy them to profiles/ afterwards
+mkdir -p $out $dst
+# headline bench line + its kernel stats + HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes)
+python3 bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
+cp $out/bench_line.json $dst/${tag}_bench_full_line.json
+rocprofv3 --kernel-trace --stats -d $out/bench -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs > $out/bench_prof.log 2>&1
+python tools/kernel_stats.py $out/bench $dst/${tag}_bench_kernel_stats.csv \
+    "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs (headline configuration only)" > /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmc_write.log 2>&1
+python tools/hbm_traffic.py $out/pmc_fetch $out/pmc_write $dst/${tag}_hbm_traffic.json > /dev/null
+echo "headline done"
+tools/profile_configs.sh $tag
