@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        11
+#define SC_ABI_VERSION        12
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -251,6 +251,20 @@ int sc_reduce_slot(const double *corr_partials, int32_t n_corr, const double *en
  * destination held on the device a launch sequence "correlate, reduce, step" has no argument that changes from step to
  * step: it is captured once in a HIP graph and replayed (HermanKlukPropagator.run(use_graph=True)). */
 int sc_reduce_slot_at(const double *corr_partials, int32_t n_corr, double *slots, int64_t *cursor, void *stream);
+
+/* The WHOLE caller loop (cli.py:401-436: nsteps times "autocorrelation, ic_correlation, step") in one launch, for
+ * separable potentials (SC_POT_MORSE / HARMONIC_SEP / EPS_MORSE) with diagonal width matrices and D <= 12: a trajectory is
+ * loaded once into registers, runs all steps there and is written back once (sc_hk_run_supported says whether the
+ * combination qualifies; everything else takes sc_hk_correlate / sc_hk_step step by step).  Arguments as for
+ * sc_hk_correlate and sc_hk_step.  partials: scratch of 5 * sc_hk_run_slots(n, D) * nsteps doubles;
+ * slots_out [nsteps][5]: row k = Re C, Im C, Re k, Im k summed over the trajectories for the state BEFORE step k (what
+ * sc_hk_correlate + sc_reduce_slot give) and the mean <T+V> at the k4 stage of step k; elog: the energy-guard log of
+ * sc_energy_guard, advanced by nsteps steps. */
+int sc_hk_run_slots(int64_t n, int32_t dim);
+int sc_hk_run_supported(const sc_potential *pot, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0);
+int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
+              const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,
+              double dt, int32_t nsteps, double *partials, double *slots_out, double *elog, void *stream);
 
 /* Walton-Manolopoulos: Filinov matrix A (eqn 50), its inverse and determinant, Gt/Gti/CQQ/M (57-78), the second
  * inverse and determinant, the trackers of sqrt(detA), sqrt(detM) and the per-trajectory terms of eqns (85), (100),

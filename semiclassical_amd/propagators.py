@@ -514,7 +514,10 @@ class HermanKlukPropagator(object):
         base = slots.data_ptr()
         fused = hasattr(potential, "_descriptor") and not hasattr(potential, "_gdml_model") and self.dim <= 64
         desc = self._potential_descriptor(potential, dt) if fused else None
-        if use_graph and fused and nt > 2 and not getattr(self, "profile_step_kernel", False) and not self.kernel_timing:
+        if fused and self._whole_loop_applies(desc):
+            # separable potential, diagonal widths, D <= 12: the whole loop as ONE launch (sc_hk_run)
+            self._run_whole_loop(desc, dt, nt, slots)
+        elif use_graph and fused and nt > 2 and not getattr(self, "profile_step_kernel", False) and not self.kernel_timing:
             self._run_graph(potential, dt, nt, desc, slots)
         else:
             for k in range(nt):
@@ -526,6 +529,27 @@ class HermanKlukPropagator(object):
             return None
         self.synchronize()
         return self.finalize_slots(slots, t0, dt, energy0_es)
+
+    _whole_loop_ok = True           # WM needs its own per-step kernel between the steps
+
+    def _whole_loop_applies(self, desc):
+        return (self._whole_loop_ok and not self.kernel_timing and not getattr(self, "profile_step_kernel", False)
+                and not self._shortcut_applies(desc)
+                and bool(lib.sc_hk_run_supported(desc, self._hk, self._ovl_t0)))
+
+    def _run_whole_loop(self, desc, dt, nt, slots):
+        self._sync_dense_mono(leave_diagonal=True)
+        self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
+        nslots = lib.sc_hk_run_slots(self.ntraj, self.dim)
+        partials = torch.empty((nt, nslots, 5), dtype=F64, device=self.device)
+        nac = self._nac
+        check(lib.sc_hk_run(desc, self._state, self._hk, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
+                            ptr(self._nacq) if nac is not None else None, self._mc_norm(), dt, nt, ptr(partials), ptr(slots),
+                            ptr(self._elog), self._stream()))
+        self._run_scratch = partials          # alive until the stream has consumed it
+        self._nsteps += nt
+        for _ in range(nt):
+            self.t += dt                      # accumulated as the reference's loop does (propagators.py:655)
 
     def _run_graph(self, potential, dt, nt, desc, slots):
         """first iteration eagerly (lazy set-up, layout conversion), then one captured iteration replayed nt - 1 times"""
@@ -741,6 +765,7 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
     """
 
     _tiled_fast_path = False        # the Filinov matrix is built from the row-major blocks after every step
+    _whole_loop_ok = False          # ... by its own kernel, between the steps
 
     def __init__(self, Gamma_i, Gamma_t, alpha, beta, device='cuda'):
         super().__init__(Gamma_i, Gamma_t, device=device)      # the Filinov matrix needs the dense monodromy blocks

@@ -476,3 +476,59 @@ def test_trajectory_cursor_under_graph_replay():
         out.append((c, k, prop._c2.clone(), prop._qp.clone()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
+
+
+@pytest.mark.parametrize("name", ["hk_as5_chi002", "hk_as5_chi000", "hk_1d"])
+def test_whole_loop_kernel_matches_stepwise_path_and_golden(name):
+    """sc_hk_run (the caller loop of cli.py:401-436 as ONE launch; separable potential, diagonal widths, D <= 12) against the
+    step-by-step launches of the same engine and against the reference's golden C(t), k_ic(t): same per-trajectory
+    arithmetic, so the state agrees to rounding of the summation order (asserted 1e-13), signs bit-exact."""
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load(name)
+    nt, dt, E0 = int(g["nt"]), float(g["dt"]), float(g["E0"])
+    fused, stepwise = engine_propagator(g), engine_propagator(g)
+    stepwise._whole_loop_ok = False
+    pot = engine_potential(g)
+    assert fused._whole_loop_applies(fused._potential_descriptor(pot, dt))
+    c1, k1 = fused.run(pot, dt, nt, E0)
+    c2, k2 = stepwise.run(pot, dt, nt, E0)
+    assert cases.rel_err(c1, c2) < 1e-13 and cases.rel_err(k1, k2) < 1e-13
+    assert cases.rel_err(c1, g["cauto"]) < 1e-9 and cases.rel_err(k1, g["kic"]) < 1e-9
+    assert torch.equal(fused._sgn, stepwise._sgn)
+    assert cases.rel_err(cnp(fused.y), cnp(stepwise.y)) < 1e-13
+    assert cases.rel_err(cnp(fused._c2), cnp(stepwise._c2)) < 1e-12
+    assert abs(fused.t - stepwise.t) == 0.0 and fused._nsteps == stepwise._nsteps
+    assert cases.rel_err(cnp(fused._elog), cnp(stepwise._elog)) < 1e-12          # the energy guard saw the same means
+    # and the loop can be continued step by step from the state the kernel left
+    fused.step(pot, dt); stepwise.step(pot, dt)
+    assert abs(fused.autocorrelation(E0) - stepwise.autocorrelation(E0)) < 1e-13 * abs(stepwise.autocorrelation(E0))
+
+
+def test_whole_loop_kernel_with_dense_blocks_and_ragged_batch():
+    """random dense monodromy blocks (the fixed-order elimination meets weak pivots: in-kernel pivoted repeat), D = 12, and
+    a batch that is not a multiple of 16"""
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(3)
+    D, n, nt, dt = 12, 203, 6, 2.0
+    omega = torch.from_numpy(np.sort(rng.uniform(500, 3000, D)) / 219474.63)
+    S = torch.from_numpy(rng.uniform(0.05, 0.4, D))
+    nac = torch.from_numpy(rng.normal(0, 1e-3, D))
+    G = torch.diag(omega)
+    q0, E0 = torch.sqrt(2 * S / omega), float(0.5 * omega.sum())
+    props = []
+    gen = torch.Generator().manual_seed(2)
+    blocks = [torch.eye(D).unsqueeze(2) * (k in (0, 3)) + 0.4 * torch.randn(D, D, n, generator=gen) for k in range(4)]
+    for whole in (True, False):
+        prop = PR.HermanKlukPropagator(G, G, device="cuda")
+        prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(5))
+        y = prop.y
+        for k, blk in enumerate(blocks):
+            y[2 * D + k * D * D: 2 * D + (k + 1) * D * D] = blk.reshape(D * D, n).cuda()
+        prop.y = y
+        prop._whole_loop_ok = whole
+        props.append((prop, prop.run(P.MorsePotential(omega, torch.full((D,), 0.02), nac), dt, nt, E0)))
+    (a, (ca, ka)), (b, (cb, kb)) = props
+    assert cases.rel_err(ca, cb) < 1e-12 and cases.rel_err(ka, kb) < 1e-12
+    assert torch.equal(a._sgn, b._sgn)
+    assert cases.rel_err(cnp(a._c2), cnp(b._c2)) < 1e-11 and cases.rel_err(cnp(a.y), cnp(b.y)) < 1e-13
