@@ -82,7 +82,8 @@ def _inject_initial_conditions(monkeypatch, zis, probis):
     return count
 
 
-@pytest.mark.parametrize("prop,tol", [("HK", 1e-8), ("WM", 1e-7)])
+# achieved on MI355X (round 3, printed below): C(t), k_ic(t), ic_rate 1.3e-15 .. 3.0e-15 for both propagators
+@pytest.mark.parametrize("prop,tol", [("HK", 1e-12), ("WM", 1e-12)])
 def test_harmonic_task_matches_reference_driver(prop, tol, tmp_path, monkeypatch):
     """Row N3: the reference's own example task (tests/DATA/examples/methylium_AH/semi.json: harmonic potential from
     three fchk files, then the rates task) through semiclassical_amd.driver, against the npz the REFERENCE's
@@ -107,10 +108,12 @@ def test_harmonic_task_matches_reference_driver(prop, tol, tmp_path, monkeypatch
     assert np.array_equal(got["times"], ref["times"])
     assert abs(float(got["zero_point_energy"]) - float(ref["zero_point_energy"])) < 1e-12
     assert abs(float(got["adiabatic_gap"]) - float(ref["adiabatic_gap"])) < 1e-10
-    assert cases.rel_err(got["autocorrelation"], ref["autocorrelation"]) < tol
-    assert cases.rel_err(got["ic_correlation"], ref["ic_correlation"]) < tol
+    e_c, e_k = cases.rel_err(got["autocorrelation"], ref["autocorrelation"]), cases.rel_err(got["ic_correlation"], ref["ic_correlation"])
+    e_r = cases.rel_err(got["ic_rate"], ref["ic_rate"])
+    print(f"driver task {prop}: achieved deviation from the reference's npz  C(t) {e_c:.2e}  k_ic(t) {e_k:.2e}  ic_rate {e_r:.2e}")
+    assert e_c < tol and e_k < tol
     assert np.array_equal(got["energies"], ref["energies"])
-    assert cases.rel_err(got["ic_rate"], ref["ic_rate"]) < 10 * tol
+    assert e_r < tol
     assert str(got["broadening"]) == str(ref["broadening"]) and float(got["hwhmG"]) == float(ref["hwhmG"])
 
 
