@@ -284,7 +284,7 @@ int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const double *zi
                     double *partials, void *stream);
 
 /* partner atoms per atom the sGDML kernel instantiated for a molecule of n_atoms atoms holds (8, 16, 20, 24 or 32);
- * -1 beyond 32 atoms, which sc_gdml_eval / sc_gdml_stage refuse */
+ * -1 beyond 48 atoms, which sc_gdml_eval / sc_gdml_stage refuse */
 int sc_gdml_row_len(int32_t n_atoms);
 
 /* E - origin [n], dE/dr [n][3N], d2E/drdr [n][3N][3N] of the sGDML model at the geometries r [n][3N].

@@ -44,17 +44,26 @@ struct GdmlLds {
 };
 
 // Launch shapes.  A geometry with 3N <= 64 (10 Hessian tiles) takes four wavefronts, two geometries share a CU; a
-// larger one (up to 32 atoms, 21 tiles) takes eight wavefronts.  Either way a wavefront holds at most three 16 x 16
-// accumulator tiles.  A chunk has one training point per wavefront (the row reductions run one point per wavefront;
-// K = 2 GDML_CH in the GEMM).
-#define GDML_MAX_TILES 3
+// larger one takes eight wavefronts.  Up to 32 atoms (21 tiles) a wavefront holds at most three 16 x 16 accumulator tiles
+// (MT = 3); 33 .. 40 atoms (36 tiles) five, 41 .. 48 atoms (45 tiles) six (round 3: the reference's predictor has no size
+// limit, gdml_predictor.py:96-250).  A chunk has one training point per wavefront (the row reductions run one point per
+// wavefront; K = 2 GDML_CH in the GEMM).
 __host__ __device__ inline int gdml_threads(int N) { return 3 * N <= 64 ? 256 : 512; }
-size_t gdml_lds_doubles_ch(int N, int Dd, int ch);
-// training points per chunk: one per wavefront; four for 32 atoms, whose eight-row stage buffers do not fit twice
+__host__ __device__ inline int gdml_tiles_per_wave(int N) { return N <= 32 ? 3 : (N <= 40 ? 5 : 6); }
+size_t gdml_lds_doubles_ch(int N, int Dd, int ch, int nb);
+// training points per chunk: one per wavefront; four where the eight-row stage buffers do not fit twice
 // (measured at 17 atoms: eight rows on four wavefronts are no faster than four)
 inline int gdml_ch(int N) {
     if (gdml_threads(N) == 256) return 4;
-    return gdml_lds_doubles_ch(N, N * (N - 1) / 2, 8) * 8 <= 160 * 1024 ? 8 : 4;
+    return gdml_lds_doubles_ch(N, N * (N - 1) / 2, 8, 2) * 8 <= 160 * 1024 ? 8 : 4;
+}
+// stage buffers: two (the copy of chunk k + 1 runs under chunk k) while they fit, one beyond (41 .. 48 atoms: the copy of
+// chunk k + 1 is started behind the last reader of chunk k and runs under the matrix-core phase only)
+// (decided for the largest molecule of the instantiation that takes N atoms, so that every N of a bucket takes the same kernel)
+extern "C" int sc_gdml_row_len(int32_t n_atoms);
+inline int gdml_nb(int N) {
+    const int nmax = sc_gdml_row_len(N) > 0 ? sc_gdml_row_len(N) : N;
+    return gdml_lds_doubles_ch(nmax, nmax * (nmax - 1) / 2, gdml_ch(nmax), 2) * 8 <= 160 * 1024 ? 2 : 1;
 }
 
 // row stride of the operand arrays: 16 T (+16) doubles with stride = 16 mod 32, so that the four rows an MFMA operand
@@ -83,15 +92,15 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int GDML_CH) {
     L.Qn = f;   f += GDML_CH * L.XP;
     L.Z = f;    f += GDML_CH * L.XP;
     if ((f - base) & 1) ++f;           // 16-byte aligned: the stage is filled by 16-byte LDS-DMA loads
-    L.stage = f;                       // [2][2][GDML_CH][Dd]: two buffers of a chunk's rows of xs_train, then of jx_alphas
+    L.stage = f;                       // [NB][2][GDML_CH][Dd]: buffers of a chunk's rows of xs_train, then of jx_alphas
     return L;
 }
 
-size_t gdml_lds_doubles_ch(int N, int Dd, int GDML_CH) {
+size_t gdml_lds_doubles_ch(int N, int Dd, int GDML_CH, int nb) {
     return 32 + 3 * N + 5 * (size_t)Dd + 4 * GDML_CH + 3 * N + (N & 1) + 9 * N + (N & 1) + 3 * (size_t)GDML_CH * gdml_xp(N) +
-           2 * 2 * (size_t)GDML_CH * Dd + 1;       // + 1: alignment pad of the stage
+           (size_t)nb * 2 * (size_t)GDML_CH * Dd + 1;       // + 1: alignment pad of the stage
 }
-size_t gdml_lds_doubles(int N, int Dd) { return gdml_lds_doubles_ch(N, Dd, gdml_ch(N)); }
+size_t gdml_lds_doubles(int N, int Dd) { return gdml_lds_doubles_ch(N, Dd, gdml_ch(N), gdml_nb(N)); }
 
 // V (without origin), grad[3N] (LDS, L.grad) and hess[3N][3N] (global, row-major) at the geometry in L.pos.
 // Every thread returns the energy.  256 threads.
@@ -103,8 +112,10 @@ size_t gdml_lds_doubles(int N, int Dd) { return gdml_lds_doubles_ch(N, Dd, gdml_
 // GEMM (gathered from the staged rows with the thread's Jacobian coefficients in registers).  Round 2 read the training
 // set three times per geometry (5.9 MB from L2 at 30 atoms / 200 points, the kernel's bound); this reads 1.4 MB.
 // HN = half of the partner atoms the instantiation holds (four threads share the partners of one atom), 2 HN >= N.
-template <int HN, int THREADS, int GDML_CH>
+// MT = accumulator tiles per wavefront, NB = stage buffers (see gdml_tiles_per_wave, gdml_nb)
+template <int HN, int THREADS, int GDML_CH, int MT, int NB>
 __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess) {
+    constexpr int GDML_MAX_TILES = MT;
     constexpr int nth = THREADS, nw = THREADS / 64;
     const int N = G.n_atoms, Dd = G.n_desc, Mt = G.n_train, X = 3 * N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -194,7 +205,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     // descriptor-space gradient g_x[d] = sum_m f_m A_m[d] - e_m XA_m (x[d] - xs_m[d]) of this thread's elements d = tid,
     // tid + 256.  The terms (2e8) cancel to the size of the force (6e1): Neumaier-compensated accumulation keeps the
     // rounding of the SUM out of the result (what remains is the rounding of the terms themselves)
-    constexpr int EPT = (512 + nth - 1) / nth;           // descriptor elements per thread (Dd <= 496)
+    constexpr int EPT = (HN * (2 * HN - 1) + nth - 1) / nth;   // descriptor elements per thread (Dd <= HN (2 HN - 1) for N <= 2 HN atoms)
     double gacc[EPT], gcomp[EPT], xown[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) { gacc[j] = 0.0; gcomp[j] = 0.0; xown[j] = tid + nth * j < Dd ? L.x[tid + nth * j] : 0.0; }
@@ -283,10 +294,15 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     // k + 1 without a barrier: different data.
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wavefront's part of the first chunk has landed
     __syncthreads();
-    for (int m0 = 0, buf = 0; m0 < Mt; m0 += GDML_CH, buf ^= 1) {
+    for (int m0 = 0, buf = 0; m0 < Mt; m0 += GDML_CH, buf = NB == 2 ? buf ^ 1 : 0) {
         const int mc = min(GDML_CH, Mt - m0);
         const double *sxs = L.stage + buf * 2 * GDML_CH * Dd, *sal = sxs + GDML_CH * Dd;
-        if (m0 + GDML_CH < Mt) stage_chunk(m0 + GDML_CH, buf ^ 1);
+        if (NB == 2) {
+            if (m0 + GDML_CH < Mt) stage_chunk(m0 + GDML_CH, buf ^ 1);
+        } else if (m0 > 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // one buffer: this chunk was requested behind the previous chunk's
+            __syncthreads();                            // last reader; everybody's part has landed
+        }
         gather_begin();
         auto gathers = [&] { sfor<0, QN>([&](auto ccc) { gather_partner(ccc, sxs, sal); }); };
         // four wavefronts: gathers between the row reductions and the scalar tail (coumarin 3.50 -> 3.35 ms per stage launch);
@@ -323,8 +339,9 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                 }
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);             // this wavefront's part of chunk k + 1 has landed
+        if (NB == 2) __builtin_amdgcn_s_waitcnt(0x0F70);   // this wavefront's part of chunk k + 1 has landed
         __syncthreads();
+        if (NB == 1 && m0 + GDML_CH < Mt) stage_chunk(m0 + GDML_CH, 0);     // nobody reads the stage any more in this chunk
         // (5) [XJ ; -e AJ]^T [Z ; XJ] of the chunk on the matrix cores: all operands of the wavefront's tiles are requested
         //     first, then the MFMAs of the tiles run interleaved (one block, no wait between the products)
 #ifndef GDML_ABLATE_MFMA
@@ -418,7 +435,7 @@ struct EvalArgs {
     double *energy, *grad, *hess;
 };
 
-template <int THREADS, int HN, int CH>
+template <int THREADS, int HN, int CH, int MT, int NB>
 __global__ __launch_bounds__(THREADS, 2) void gdml_eval_kernel(EvalArgs A) {
     extern __shared__ double smem[];
     const int X = 3 * A.G.n_atoms;
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(THREADS, 2) void gdml_eval_kernel(EvalArgs A) {
         __syncthreads();
         for (int i = threadIdx.x; i < X; i += blockDim.x) L.pos[i] = A.r[tr * X + i];
         __syncthreads();
-        const double e = gdml_eval_device<HN, THREADS, CH>(A.G, L, A.hess + (size_t)tr * X * X);
+        const double e = gdml_eval_device<HN, THREADS, CH, MT, NB>(A.G, L, A.hess + (size_t)tr * X * X);
         for (int i = threadIdx.x; i < X; i += blockDim.x) A.grad[tr * X + i] = L.grad[i];
         if (threadIdx.x == 0) A.energy[tr] = e - A.G.origin;
     }
@@ -443,7 +460,7 @@ struct StageArgs {
     double *epart;
 };
 
-template <int THREADS, int HN, int CH>
+template <int THREADS, int HN, int CH, int MT, int NB>
 __global__ __launch_bounds__(THREADS, 2) void gdml_stage_kernel(StageArgs A) {
     extern __shared__ double smem[];
     const int D = A.st.dim, tid = threadIdx.x, nth = blockDim.x, s = A.stage;
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(THREADS, 2) void gdml_stage_kernel(StageArgs A) {
             ps[j] = qp[D + i] + c * kp;
         }
         __syncthreads();
-        const double e = gdml_eval_device<HN, THREADS, CH>(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D) - A.G.origin;
+        const double e = gdml_eval_device<HN, THREADS, CH, MT, NB>(A.G, L, A.sc.hess + ((size_t)tr * 4 + s) * D * D) - A.G.origin;
         double tk[1] = {0.0};
         for (int i = tid, j = 0; i < D; i += nth, ++j) {
             const double im = A.G.inv_mass[i], kq = ps[j] * im, kp = -L.grad[i];
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(THREADS, 2) void gdml_stage_kernel(StageArgs A) {
 }  // namespace
 
 extern "C" int sc_gdml_row_len(int32_t n_atoms) {
-    for (int len : {8, 16, 20, 24, 32})
+    for (int len : {8, 16, 20, 24, 32, 40, 48})
         if (n_atoms <= len) return len;
     return -1;
 }
@@ -495,7 +512,8 @@ namespace {
 int check_model(const sc_gdml_model *g, const char *who) {
     if (!g || !g->xs_train || !g->jx_alphas || !g->pair_k || !g->pair_l)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: null model field", who);
-    if (g->n_atoms > 32) return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms (four threads hold the coefficients of 32 partner atoms)", who, g->n_atoms);
+    if (g->n_atoms > 48) return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms (the instantiated kernels hold up to 48: four threads keep the "
+                                        "Jacobian coefficients of an atom's partners in registers, a workgroup the chunk's rows in LDS)", who, g->n_atoms);
     if (((uintptr_t)g->xs_train | (uintptr_t)g->jx_alphas) & 15)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "%s: xs_train / jx_alphas must be 16-byte aligned", who);
     if (g->n_desc != g->n_atoms * (g->n_atoms - 1) / 2)
@@ -504,7 +522,7 @@ int check_model(const sc_gdml_model *g, const char *who) {
         return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d) needs more than 160 KiB of LDS", who, g->n_atoms);
     {
         const int T = (3 * g->n_atoms + 15) / 16;
-        if (T * (T + 1) / 2 > GDML_MAX_TILES * (gdml_threads(g->n_atoms) / 64))
+        if (T * (T + 1) / 2 > gdml_tiles_per_wave(g->n_atoms) * (gdml_threads(g->n_atoms) / 64))
             return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms need more Hessian tiles than the kernel holds", who, g->n_atoms);
     }
     return SC_OK;
@@ -521,18 +539,19 @@ extern "C" int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, 
     const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc) * 8;
     EvalArgs a{*g, r, n, energy, grad, hess};
     const int grid = (int)(n < 1024 ? n : 1024);
-#define SC_GDML_EVAL(TH_, HN_, CH_)                                                                                        \
-    if (threads == TH_ && row_len == 2 * HN_ && ch == CH_) {                                                               \
-        if (hipFuncSetAttribute((const void *)gdml_eval_kernel<TH_, HN_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+#define SC_GDML_EVAL(TH_, HN_, CH_, MT_, NB_)                                                                                       \
+    if (threads == TH_ && row_len == 2 * HN_ && ch == CH_ && nb == NB_) {                                                             \
+        if (hipFuncSetAttribute((const void *)gdml_eval_kernel<TH_, HN_, CH_, MT_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds) != hipSuccess)                                                                   \
             return sc_check_launch("sc_gdml_eval (LDS attribute)");                                                        \
-        hipLaunchKernelGGL((gdml_eval_kernel<TH_, HN_, CH_>), dim3(grid), dim3(TH_), lds, (hipStream_t)stream, a);         \
+        hipLaunchKernelGGL((gdml_eval_kernel<TH_, HN_, CH_, MT_, NB_>), dim3(grid), dim3(TH_), lds, (hipStream_t)stream, a);         \
         launched = true;                                                                                                   \
     }
-    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms);
+    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms), nb = gdml_nb(g->n_atoms);
     bool launched = false;
-    SC_GDML_EVAL(256, 4, 4) SC_GDML_EVAL(256, 8, 4) SC_GDML_EVAL(256, 10, 4) SC_GDML_EVAL(256, 12, 4)
-    SC_GDML_EVAL(512, 12, 8) SC_GDML_EVAL(512, 16, 8) SC_GDML_EVAL(512, 16, 4)
+    SC_GDML_EVAL(256, 4, 4, 3, 2) SC_GDML_EVAL(256, 8, 4, 3, 2) SC_GDML_EVAL(256, 10, 4, 3, 2) SC_GDML_EVAL(256, 12, 4, 3, 2)
+    SC_GDML_EVAL(512, 12, 8, 3, 2) SC_GDML_EVAL(512, 16, 8, 3, 2) SC_GDML_EVAL(512, 16, 4, 3, 2)
+    SC_GDML_EVAL(512, 20, 4, 5, 2) SC_GDML_EVAL(512, 24, 4, 6, 1)
 #undef SC_GDML_EVAL
     if (!launched) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_eval: no kernel for %d atoms", g->n_atoms);
     return sc_check_launch("sc_gdml_eval");
@@ -552,18 +571,19 @@ extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const s
     if (st->n <= 0) return SC_OK;
     const size_t lds = gdml_lds_doubles(g->n_atoms, g->n_desc) * 8;
     StageArgs a{*g, *st, *sc, dt, stage, energy_partials};
-#define SC_GDML_STAGE(TH_, HN_, CH_)                                                                                       \
-    if (threads == TH_ && row_len == 2 * HN_ && ch == CH_) {                                                               \
-        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<TH_, HN_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+#define SC_GDML_STAGE(TH_, HN_, CH_, MT_, NB_)                                                                                      \
+    if (threads == TH_ && row_len == 2 * HN_ && ch == CH_ && nb == NB_) {                                                             \
+        if (hipFuncSetAttribute((const void *)gdml_stage_kernel<TH_, HN_, CH_, MT_, NB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds) != hipSuccess)                                                                   \
             return sc_check_launch("sc_gdml_stage (LDS attribute)");                                                       \
-        hipLaunchKernelGGL((gdml_stage_kernel<TH_, HN_, CH_>), dim3(sc_dense_grid(st->n)), dim3(TH_), lds, (hipStream_t)stream, a); \
+        hipLaunchKernelGGL((gdml_stage_kernel<TH_, HN_, CH_, MT_, NB_>), dim3(sc_dense_grid(st->n)), dim3(TH_), lds, (hipStream_t)stream, a); \
         launched = true;                                                                                                   \
     }
-    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms);
+    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms), nb = gdml_nb(g->n_atoms);
     bool launched = false;
-    SC_GDML_STAGE(256, 4, 4) SC_GDML_STAGE(256, 8, 4) SC_GDML_STAGE(256, 10, 4) SC_GDML_STAGE(256, 12, 4)
-    SC_GDML_STAGE(512, 12, 8) SC_GDML_STAGE(512, 16, 8) SC_GDML_STAGE(512, 16, 4)
+    SC_GDML_STAGE(256, 4, 4, 3, 2) SC_GDML_STAGE(256, 8, 4, 3, 2) SC_GDML_STAGE(256, 10, 4, 3, 2) SC_GDML_STAGE(256, 12, 4, 3, 2)
+    SC_GDML_STAGE(512, 12, 8, 3, 2) SC_GDML_STAGE(512, 16, 8, 3, 2) SC_GDML_STAGE(512, 16, 4, 3, 2)
+    SC_GDML_STAGE(512, 20, 4, 5, 2) SC_GDML_STAGE(512, 24, 4, 6, 1)
 #undef SC_GDML_STAGE
     if (!launched) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_stage: no kernel for %d atoms", g->n_atoms);
     return sc_check_launch("sc_gdml_stage");

@@ -33,7 +33,7 @@ class MolecularGDMLPotential(_MolecularPotentialBase):
         self._jx_alphas = expand(torch.tensor(np.asarray(model['R_d_desc_alpha'], dtype=np.float64)))
         self._sig, self._c, self._std = int(model['sig']), float(model['c']), float(model.get('std', 1))
         self._n_atoms = int(n_atoms)
-        assert lib.sc_gdml_row_len(self._n_atoms) > 0, "the sGDML kernels hold molecules of up to 32 atoms"
+        assert lib.sc_gdml_row_len(self._n_atoms) > 0, "the sGDML kernels hold molecules of up to 48 atoms"
         k, l = torch.tril_indices(n_atoms, n_atoms, offset=-1)
         self._pair_k, self._pair_l = k.to(torch.int32).contiguous(), l.to(torch.int32).contiguous()
         self._default_device = device

@@ -132,11 +132,13 @@ def test_gdml_30_atoms_matches_oracle():
     assert dy < TOL30[3] and dc2 < TOL30[4]
 
 
-@pytest.mark.parametrize("N,M", [(5, 37), (12, 50), (19, 61), (21, 44), (22, 40), (24, 83), (28, 70), (31, 29), (32, 45), (32, 3)])
+@pytest.mark.parametrize("N,M", [(5, 37), (12, 50), (19, 61), (21, 44), (22, 40), (24, 83), (28, 70), (31, 29), (32, 45), (32, 3),
+                                 (33, 18), (40, 23), (41, 14), (44, 9), (48, 22)])
 def test_gdml_launch_shapes_and_partial_chunks(N, M):
     """every instantiation of the sGDML kernels (4 or 8 wavefronts per geometry, 4 or 8 training points per chunk, the
-    partner-coefficient counts of 8 ... 32 atoms) with a training-set size that leaves a partial last chunk: E, grad,
-    Hessian against the CPU oracle on a synthetic model"""
+    partner-coefficient counts of 8 ... 48 atoms, 3 / 5 / 6 Hessian tiles per wavefront, two stage buffers or -- beyond 40
+    atoms -- one) with a training-set size that leaves a partial last chunk: E, grad, Hessian against the CPU oracle on a
+    synthetic model.  (Round 2 stopped at 32 atoms; the reference's predictor has no limit, gdml_predictor.py:96-250.)"""
     from oracle import sc_oracle as orc
     from semiclassical_amd.gdml import MolecularGDMLPotential
     torch.set_default_dtype(torch.float64)
