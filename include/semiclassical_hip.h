@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        12
+#define SC_ABI_VERSION        13
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -330,6 +330,12 @@ int sc_hk_step_diag(const sc_potential *pot, const sc_state *st, const sc_hk_con
  * HermanKlukPropagator.norm() (propagators.py:734-782): X1/Y1 [n][K1], X2/Y2 [n][K2] real, rs/ib/ik [n] real,
  * wb/wk [n] complex; partials[sc_pair_sum_tiles(n)][4] (re, im, 0, 0) for sc_reduce_slot. */
 int64_t sc_pair_sum_tiles(int64_t n);
+/* ... and over bras i of one set of trajectories (X operands, rs_i, ib, wb: ni rows) and kets j of another (Y operands,
+ * rs_j, ik, wk: nj rows): a rank's shard against the gathered ensemble, for norm() across ranks. */
+int64_t sc_pair_sum_rect_tiles(int64_t ni, int64_t nj);
+int sc_pair_sum_rect(const double *X1, const double *Y1, int32_t K1, const double *X2, const double *Y2, int32_t K2,
+                     const double *rs_i, const double *rs_j, const double *ib, const double *ik, const double *wb,
+                     const double *wk, int64_t ni, int64_t nj, double *partials, void *stream);
 int sc_pair_sum(const double *X1, const double *Y1, int32_t K1, const double *X2, const double *Y2, int32_t K2,
                 const double *rs, const double *ib, const double *ik, const double *wb, const double *wk,
                 int64_t n, double *partials, void *stream);
@@ -350,6 +356,13 @@ int sc_wm_grid_sum(const double *qp, const double *coef, const double *cqq, cons
  * export of sc_wm_correlate and its projections cqqp [n][d'][d'] = U^T CQQ U, dvecp [n][d'] = U^T dvec (complex),
  * U [D][d'] real.  partials [sc_wm_pair_sum_tiles(n)][4] for sc_reduce_slot.  D <= 64, d' <= 16. */
 int64_t sc_wm_pair_sum_tiles(int64_t n);
+/* The same pair sum over bras i of one set of trajectories and kets j of another (a rank's shard against the gathered
+ * ensemble: norm() across ranks); partials [sc_wm_pair_sum_rect_tiles(ni, nj)][4]. */
+int64_t sc_wm_pair_sum_rect_tiles(int64_t ni, int64_t nj);
+int sc_wm_pair_sum_rect(const double *qp_i, const double *coef_i, const double *cqqp_i, const double *dvecp_i, int64_t ni,
+                        const double *qp_j, const double *coef_j, const double *cqq_j, const double *dvec_j,
+                        const double *cqqp_j, const double *dvecp_j, int64_t nj, const double *U, int32_t D,
+                        int32_t dprime, double *partials, void *stream);
 int sc_wm_pair_sum(const double *qp, const double *coef, const double *cqq, const double *dvec, const double *cqqp,
                    const double *dvecp, const double *U, int64_t n, int32_t D, int32_t dprime, double *partials,
                    void *stream);

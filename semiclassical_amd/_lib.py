@@ -72,7 +72,7 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 12              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 13              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 
@@ -123,6 +123,13 @@ SIGNATURES = {
     "sc_dense_mono_step": (C.c_int, [P(sc_state), P(sc_hk_consts), c_double_p, c_double_p, c_double_p, C.c_double,
                                      C.c_int32, C.c_void_p]),
     "sc_pair_sum_tiles": (C.c_int64, [C.c_int64]),
+    "sc_pair_sum_rect_tiles": (C.c_int64, [C.c_int64, C.c_int64]),
+    "sc_pair_sum_rect": (C.c_int, [c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p,
+                                   c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int64, c_double_p, C.c_void_p]),
+    "sc_wm_pair_sum_rect_tiles": (C.c_int64, [C.c_int64, C.c_int64]),
+    "sc_wm_pair_sum_rect": (C.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_double_p, C.c_int64, c_double_p, C.c_int32, C.c_int32, c_double_p,
+                                      C.c_void_p]),
     "sc_pair_sum": (C.c_int, [c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p,
                               c_double_p, c_double_p, c_double_p, c_double_p, C.c_int64, c_double_p, C.c_void_p]),
     "sc_hk_step_diag": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), c_double_p, C.c_double, C.c_int32,

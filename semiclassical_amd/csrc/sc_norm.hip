@@ -11,11 +11,11 @@
 namespace {
 
 struct PairArgs {
-    const double *X1, *Y1, *X2, *Y2;    // [n][K1], [n][K1], [n][K2], [n][K2]
+    const double *X1, *Y1, *X2, *Y2;    // [ni][K1], [nj][K1], [ni][K2], [nj][K2]
     int K1, K2;
-    const double *rs, *ib, *ik;         // [n] real
-    const double *wb, *wk;              // [n] complex
-    int64_t n;
+    const double *rsi, *rsj, *ib, *ik;  // [ni], [nj], [ni], [nj] real
+    const double *wb, *wk;              // [ni], [nj] complex
+    int64_t ni, nj;                     // bras i (rows of the X operands), kets j (rows of the Y operands)
     double *partials;                   // [tiles][4], columns 2, 3 are zero
 };
 
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs A) {
     __shared__ double xs[PK][PT + 1], ys[PK][PT + 1];
     __shared__ double red[32];
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-    const int64_t tiles = (A.n + PT - 1) / PT;
+    const int64_t tiles = (A.nj + PT - 1) / PT;
     const int64_t bi = blockIdx.x / tiles, bj = blockIdx.x % tiles;
     const int64_t i0 = bi * PT, j0 = bj * PT;
     double re[4][4], im[4][4];
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs A) {
             for (int e = tid; e < PK * PT; e += 256) {
                 const int r = e / PK, k = e - r * PK;            // row r of the tile, column k of the chunk
                 const bool kin = k0 + k < K;
-                xs[k][r] = (kin && i0 + r < A.n) ? X[(i0 + r) * K + k0 + k] : 0.0;
-                ys[k][r] = (kin && j0 + r < A.n) ? Y[(j0 + r) * K + k0 + k] : 0.0;
+                xs[k][r] = (kin && i0 + r < A.ni) ? X[(i0 + r) * K + k0 + k] : 0.0;
+                ys[k][r] = (kin && j0 + r < A.nj) ? Y[(j0 + r) * K + k0 + k] : 0.0;
             }
             __syncthreads();
 #pragma unroll
@@ -65,14 +65,14 @@ __global__ __launch_bounds__(256) void pair_sum_kernel(PairArgs A) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int64_t i = i0 + 4 * ti + a;
-        if (i >= A.n) continue;
+        if (i >= A.ni) continue;
         const cplx wb = ((const cplx *)A.wb)[i];
-        const double rsi = A.rs[i], ibi = A.ib[i];
+        const double rsi = A.rsi[i], ibi = A.ib[i];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int64_t j = j0 + 4 * tj + b;
-            if (j >= A.n) continue;
-            const cplx e = c_exp(c_make(rsi + A.rs[j] + re[a][b], ibi + A.ik[j] + im[a][b]));
+            if (j >= A.nj) continue;
+            const cplx e = c_exp(c_make(rsi + A.rsj[j] + re[a][b], ibi + A.ik[j] + im[a][b]));
             const cplx t = c_mul(c_mul(wb, ((const cplx *)A.wk)[j]), e);
             acc[0] += t.x; acc[1] += t.y;
         }
@@ -164,16 +164,23 @@ extern "C" int64_t sc_pair_sum_tiles(int64_t n) {
     const int64_t t = (n + PT - 1) / PT;
     return t * t;
 }
+extern "C" int64_t sc_pair_sum_rect_tiles(int64_t ni, int64_t nj) { return ((ni + PT - 1) / PT) * ((nj + PT - 1) / PT); }
+
+extern "C" int sc_pair_sum_rect(const double *X1, const double *Y1, int32_t K1, const double *X2, const double *Y2, int32_t K2,
+                                const double *rs_i, const double *rs_j, const double *ib, const double *ik, const double *wb,
+                                const double *wk, int64_t ni, int64_t nj, double *partials, void *stream) {
+    if (!X1 || !Y1 || !X2 || !Y2 || !rs_i || !rs_j || !ib || !ik || !wb || !wk || !partials)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_pair_sum: null argument");
+    if (ni <= 0 || nj <= 0) return SC_OK;
+    const int64_t tiles = sc_pair_sum_rect_tiles(ni, nj);
+    if (tiles > 0x7fffffff) return sc_fail(SC_ERR_UNSUPPORTED, "sc_pair_sum: %lld x %lld pairs need more than 2^31 tiles", (long long)ni, (long long)nj);
+    PairArgs a{X1, Y1, X2, Y2, K1, K2, rs_i, rs_j, ib, ik, wb, wk, ni, nj, partials};
+    hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    return sc_check_launch("sc_pair_sum");
+}
 
 extern "C" int sc_pair_sum(const double *X1, const double *Y1, int32_t K1, const double *X2, const double *Y2, int32_t K2,
                            const double *rs, const double *ib, const double *ik, const double *wb, const double *wk,
                            int64_t n, double *partials, void *stream) {
-    if (!X1 || !Y1 || !X2 || !Y2 || !rs || !ib || !ik || !wb || !wk || !partials)
-        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_pair_sum: null argument");
-    if (n <= 0) return SC_OK;
-    const int64_t tiles = sc_pair_sum_tiles(n);
-    if (tiles > 0x7fffffff) return sc_fail(SC_ERR_UNSUPPORTED, "sc_pair_sum: n=%lld needs more than 2^31 tiles", (long long)n);
-    PairArgs a{X1, Y1, X2, Y2, K1, K2, rs, ib, ik, wb, wk, n, partials};
-    hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
-    return sc_check_launch("sc_pair_sum");
+    return sc_pair_sum_rect(X1, Y1, K1, X2, Y2, K2, rs, rs, ib, ik, wb, wk, n, n, partials, stream);
 }

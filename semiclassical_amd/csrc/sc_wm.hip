@@ -431,8 +431,9 @@ __global__ __launch_bounds__(256) void wm_grid_sum_kernel(WmGridArgs A) {
 #define WMN_MAXD 64
 #define WMN_MAXDP 16
 struct WmPairArgs {
-    const double *qp, *coef, *cqq, *dvec, *cqqp, *dvecp, *U;
-    int64_t n;
+    const double *qp_i, *coef_i, *cqqp_i, *dvecp_i;                       // bras i: [ni] ...
+    const double *qp, *coef, *cqq, *dvec, *cqqp, *dvecp, *U;               // kets j: [nj] ...
+    int64_t ni, n;
     int D, dp;
     double *partials;
 };
@@ -443,11 +444,11 @@ __global__ __launch_bounds__(256) void wm_pair_sum_kernel(WmPairArgs A) {
     const int64_t tiles = (A.n + 15) / 16;
     const int64_t i = (blockIdx.x / tiles) * 16 + (tid >> 4), j = (blockIdx.x % tiles) * 16 + (tid & 15);
     double acc[2] = {0.0, 0.0};
-    if (i < A.n && j < A.n) {
-        const double *Qi = A.qp + i * 2 * D, *Qj = A.qp + j * 2 * D;
+    if (i < A.ni && j < A.n) {
+        const double *Qi = A.qp_i + i * 2 * D, *Qj = A.qp + j * 2 * D;
         const cplx *Cj = (const cplx *)A.cqq + j * (int64_t)D * D, *dj = (const cplx *)A.dvec + j * D;
-        const cplx *Cpi = (const cplx *)A.cqqp + i * (int64_t)dp * dp, *Cpj = (const cplx *)A.cqqp + j * (int64_t)dp * dp;
-        const cplx *dpi = (const cplx *)A.dvecp + i * dp, *dpj = (const cplx *)A.dvecp + j * dp;
+        const cplx *Cpi = (const cplx *)A.cqqp_i + i * (int64_t)dp * dp, *Cpj = (const cplx *)A.cqqp + j * (int64_t)dp * dp;
+        const cplx *dpi = (const cplx *)A.dvecp_i + i * dp, *dpj = (const cplx *)A.dvecp + j * dp;
         cplx w[WMN_MAXD], Dm[WMN_MAXDP * WMN_MAXDP], b[WMN_MAXDP];
         cplx quad = c_make(0, 0), djq = c_make(0, 0);
         for (int a = 0; a < D; ++a) {
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void wm_pair_sum_kernel(WmPairArgs A) {
             const cplx dets = c_scale(det, scale);                 // det(D'/(2 pi))
             const cplx ex = c_make(-0.5 * quad.x - djq.x + 0.5 * bib.x, -0.5 * quad.y - djq.y + 0.5 * bib.y);
             const cplx ol = c_mul(c_inv(c_sqrt(dets)), c_exp(ex));
-            const cplx vi = ((const cplx *)A.coef)[i], vj = ((const cplx *)A.coef)[j];
+            const cplx vi = ((const cplx *)A.coef_i)[i], vj = ((const cplx *)A.coef)[j];
             const cplx t = c_mul(c_mul(c_conj(vi), ol), vj);
             acc[0] = t.x; acc[1] = t.y;
         }
@@ -525,20 +526,28 @@ extern "C" int64_t sc_wm_pair_sum_tiles(int64_t n) {
     const int64_t t = (n + 15) / 16;
     return t * t;
 }
+extern "C" int64_t sc_wm_pair_sum_rect_tiles(int64_t ni, int64_t nj) { return ((ni + 15) / 16) * ((nj + 15) / 16); }
+
+extern "C" int sc_wm_pair_sum_rect(const double *qp_i, const double *coef_i, const double *cqqp_i, const double *dvecp_i, int64_t ni,
+                                   const double *qp_j, const double *coef_j, const double *cqq_j, const double *dvec_j,
+                                   const double *cqqp_j, const double *dvecp_j, int64_t nj, const double *U, int32_t D,
+                                   int32_t dprime, double *partials, void *stream) {
+    if (!qp_i || !coef_i || !cqqp_i || !dvecp_i || !qp_j || !coef_j || !cqq_j || !dvec_j || !cqqp_j || !dvecp_j || !U || !partials)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_pair_sum: null argument");
+    if (D < 1 || D > WMN_MAXD || dprime < 1 || dprime > WMN_MAXDP || dprime > D)
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_pair_sum: D=%d d'=%d outside D <= %d, d' <= %d", D, dprime, WMN_MAXD, WMN_MAXDP);
+    if (ni <= 0 || nj <= 0) return SC_OK;
+    const int64_t tiles = sc_wm_pair_sum_rect_tiles(ni, nj);
+    if (tiles > 0x7fffffff) return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_pair_sum: %lld x %lld pairs need more than 2^31 tiles", (long long)ni, (long long)nj);
+    WmPairArgs a{qp_i, coef_i, cqqp_i, dvecp_i, qp_j, coef_j, cqq_j, dvec_j, cqqp_j, dvecp_j, U, ni, nj, D, dprime, partials};
+    hipLaunchKernelGGL(wm_pair_sum_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    return sc_check_launch("sc_wm_pair_sum");
+}
 
 extern "C" int sc_wm_pair_sum(const double *qp, const double *coef, const double *cqq, const double *dvec,
                               const double *cqqp, const double *dvecp, const double *U, int64_t n, int32_t D,
                               int32_t dprime, double *partials, void *stream) {
-    if (!qp || !coef || !cqq || !dvec || !cqqp || !dvecp || !U || !partials)
-        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_pair_sum: null argument");
-    if (D < 1 || D > WMN_MAXD || dprime < 1 || dprime > WMN_MAXDP || dprime > D)
-        return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_pair_sum: D=%d d'=%d outside D <= %d, d' <= %d", D, dprime, WMN_MAXD, WMN_MAXDP);
-    if (n <= 0) return SC_OK;
-    const int64_t tiles = sc_wm_pair_sum_tiles(n);
-    if (tiles > 0x7fffffff) return sc_fail(SC_ERR_UNSUPPORTED, "sc_wm_pair_sum: n=%lld needs more than 2^31 tiles", (long long)n);
-    WmPairArgs a{qp, coef, cqq, dvec, cqqp, dvecp, U, n, D, dprime, partials};
-    hipLaunchKernelGGL(wm_pair_sum_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
-    return sc_check_launch("sc_wm_pair_sum");
+    return sc_wm_pair_sum_rect(qp, coef, cqqp, dvecp, n, qp, coef, cqq, dvec, cqqp, dvecp, n, U, D, dprime, partials, stream);
 }
 
 extern "C" int sc_wm_grid_sum(const double *qp, const double *coef, const double *cqq, const double *dvec, int64_t n,

@@ -127,3 +127,40 @@ def flush_correlations(slots, group=None):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     slots[:, :4] = buf
     return slots
+
+
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def all_gather_rows(t, group=None):
+    """the rows (first axis) of ``t`` of all ranks, concatenated in rank order, on ``t``'s device.  Shards may differ in
+    size.  Under ``gloo`` device tensors are staged through the host (as in flush_correlations)."""
+    if not _active(group):
+        return t
+    world = dist.get_world_size(group)
+    stage = t.is_cuda and dist.get_backend(group) == "gloo"
+    src = t.contiguous().cpu() if stage else t.contiguous()
+    counts = [torch.zeros(1, dtype=torch.int64, device=src.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([src.shape[0]], dtype=torch.int64, device=src.device), group=group)
+    counts = [int(c.item()) for c in counts]
+    width = max(counts)
+    pad = torch.zeros((width,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    pad[:src.shape[0]] = src
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    return out.to(t.device) if stage else out
+
+
+def all_reduce_sum(t, group=None):
+    """sum of ``t`` over the ranks, in place (staged through the host under gloo)"""
+    if not _active(group):
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

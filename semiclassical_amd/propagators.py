@@ -648,16 +648,24 @@ class HermanKlukPropagator(object):
         v = self.semiclassical_prefactor() * torch.exp(1j / hbar * self._act) * self._vi
         return v / (self._mc_norm() * self.probi)
 
-    def norm(self):
+    def norm(self, group=None):
         """|psi| = sqrt(sum_ij v_i^* <q_i,p_i,Gamma_t|q_j,p_j,Gamma_t> v_j), O(n^2) (reference propagators.py:734-782).
 
-        The pair sum runs in ``sc_pair_sum``; the host only packs the operands: positions are centred (the overlaps
+        The pair sum runs in ``sc_pair_sum_rect``; the host only packs the operands: positions are centred (the overlaps
         depend on differences) so that the per-trajectory and the cross terms of the exponent stay small.
+
+        Across ranks (``torch.distributed`` initialised, every rank holding one shard of the ensemble with the global N as
+        ``ntraj_total``): the ket operands of all ranks are all-gathered, every rank sums ITS bras against ALL kets and
+        one all-reduce adds the partial sums -- every rank returns the norm of the whole wavefunction.
         """
+        from . import distributed as Dm
         dev, d, n = self.device, self.dim, self.ntraj
         oc = hostmath.OverlapConstants(self._Gt, self._Gt)
         A, B, Cm = (m.to(dev) for m in (oc.A, oc.B, oc.C))
-        q = self._qp[:, :d] - self._qp[:, :d].mean(0, keepdim=True)
+        # a centre all ranks agree on: the mean position of the whole ensemble
+        qsum = torch.cat((self._qp[:, :d].sum(0), torch.tensor([float(n)], dtype=F64, device=dev)))
+        Dm.all_reduce_sum(qsum, group)
+        q = self._qp[:, :d] - (qsum[:d] / qsum[d]).unsqueeze(0)
         p = self._qp[:, d:]
         Aq, Bp, Cp = q @ A.T, p @ B.T / hbar ** 2, p @ Cm.T / hbar
         # exponent_ij = rs_i + rs_j + X1_i.Y1_j + i (ib_i + ik_j + X2_i.Y2_j)   (propagators.py:232-237 expanded)
@@ -671,13 +679,21 @@ class HermanKlukPropagator(object):
         ik = (cc - (p * q).sum(1) / hbar).contiguous()
         v = self.coefficients()
         wb, wk = (oc.fac * v.conj()).contiguous(), v.contiguous()
-        tiles = lib.sc_pair_sum_tiles(n)
+        # kets of the whole ensemble (this rank's own when there is one rank)
+        ket = torch.cat((Y1, Y2, rs.unsqueeze(1), ik.unsqueeze(1), torch.view_as_real(wk)), 1)
+        ket = Dm.all_gather_rows(ket, group)
+        nj = ket.shape[0]
+        Y1j, Y2j = ket[:, :2 * d].contiguous(), ket[:, 2 * d:5 * d].contiguous()
+        rsj, ikj = ket[:, 5 * d].contiguous(), ket[:, 5 * d + 1].contiguous()
+        wkj = ket[:, 5 * d + 2:5 * d + 4].contiguous()
+        tiles = lib.sc_pair_sum_rect_tiles(n, nj)
         partials = torch.empty((tiles, 4), dtype=F64, device=dev)
         slot = torch.zeros(8, dtype=F64, device=dev)
         s = self._stream()
-        check(lib.sc_pair_sum(ptr(X1), ptr(Y1), 2 * d, ptr(X2), ptr(Y2), 3 * d, ptr(rs), ptr(ib), ptr(ik),
-                              ptr(wb), ptr(wk), n, ptr(partials), s))
+        check(lib.sc_pair_sum_rect(ptr(X1), ptr(Y1j), 2 * d, ptr(X2), ptr(Y2j), 3 * d, ptr(rs), ptr(rsj), ptr(ib), ptr(ikj),
+                                   ptr(wb), ptr(wkj), n, nj, ptr(partials), s))
         check(lib.sc_reduce_slot(ptr(partials), int(tiles), None, 0, 1.0, ptr(slot), s))
+        Dm.all_reduce_sum(slot, group)
         return float(torch.sqrt(slot[0]).item())
 
     def wavefunction(self, x):
@@ -864,21 +880,31 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
                                  self._stream()))
         return phi.cpu().numpy()
 
-    def norm(self):
-        """norm |psi| of the WM wavefunction, O(n^2) with a d' x d' inverse per pair (reference :1484-1575)"""
+    def norm(self, group=None):
+        """norm |psi| of the WM wavefunction, O(n^2) with a d' x d' inverse per pair (reference :1484-1575); across ranks as
+        HermanKlukPropagator.norm: every rank sums its bras against the all-gathered kets, one all-reduce"""
+        from . import distributed as Dm
         dev, n, d = self.device, self.ntraj, self.dim
         coef, cqq, dvec = self._export()
         U = self._wm_bufs["U"]                                   # (D, d') real
         Uc = U.type(C128)
+        dp = U.shape[1]
         cqqp = torch.einsum('ak,nab,bl->nkl', Uc, cqq, Uc).contiguous()      # U^T CQQ U per trajectory
         dvecp = (dvec @ Uc).contiguous()
-        tiles = lib.sc_wm_pair_sum_tiles(n)
+        flat = lambda t: torch.view_as_real(t.contiguous()).reshape(t.shape[0], -1)
+        ket = torch.cat((self._qp, flat(coef.unsqueeze(1)), flat(cqq), flat(dvec), flat(cqqp), flat(dvecp)), 1)
+        ket = Dm.all_gather_rows(ket, group)
+        nj = ket.shape[0]
+        widths = [2 * d, 2, 2 * d * d, 2 * d, 2 * dp * dp, 2 * dp]
+        qpj, coefj, cqqj, dvecj, cqqpj, dvecpj = (c.contiguous() for c in torch.split(ket, widths, dim=1))
+        tiles = lib.sc_wm_pair_sum_rect_tiles(n, nj)
         partials = torch.empty((tiles, 4), dtype=F64, device=dev)
         slot = torch.zeros(8, dtype=F64, device=dev)
         s = self._stream()
-        check(lib.sc_wm_pair_sum(ptr(self._qp), ptr(coef), ptr(cqq), ptr(dvec), ptr(cqqp), ptr(dvecp), ptr(U), n, d,
-                                 U.shape[1], ptr(partials), s))
+        check(lib.sc_wm_pair_sum_rect(ptr(self._qp), ptr(coef), ptr(cqqp), ptr(dvecp), n, ptr(qpj), ptr(coefj), ptr(cqqj),
+                                      ptr(dvecj), ptr(cqqpj), ptr(dvecpj), nj, ptr(U), d, dp, ptr(partials), s))
         check(lib.sc_reduce_slot(ptr(partials), int(tiles), None, 0, 1.0, ptr(slot), s))
+        Dm.all_reduce_sum(slot, group)
         return float(torch.sqrt(slot[0]).item())
 
     def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None):

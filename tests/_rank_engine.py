@@ -45,8 +45,16 @@ def main():
     prop.synchronize()
     assert float(slots[0, 4]) == rank + 1.0
     cauto, kic = prop.finalize_slots(slots, 0.0, dt, E0)
+    # the O(n^2) diagnostic across ranks: own bras against the all-gathered kets, one all-reduce (every rank gets the whole norm)
+    norm = prop.norm() if os.environ.get("SC_TEST_NORM") else float("nan")
+    norms = [None] * world
+    if world > 1:
+        dist.all_gather_object(norms, norm)
+    else:
+        norms = [norm]
     if rank == 0:
-        np.savez(out, cauto=cauto, kic=kic, world=world, backend=dist.get_backend() if world > 1 else "none")
+        np.savez(out, cauto=cauto, kic=kic, world=world, backend=dist.get_backend() if world > 1 else "none",
+                 norms=np.array(norms, dtype=float))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

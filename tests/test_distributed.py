@@ -127,11 +127,20 @@ def test_two_engine_ranks_on_one_gpu(case, tol, tmp_path):
     g = cases.load(case)
     nt = min(12, len(g["cauto"]))
     out = str(tmp_path / "flush.npz")
+    with_norm = case != "hk_as60"                # the O(n^2) norm of the small cases only
     rc = D.launch_local_ranks([os.path.join(ROOT, "tests", "_rank_engine.py"), case, str(nt), out], 2, timeout=600,
-                              extra_env={"SC_DIST_BACKEND": "gloo", "SC_TEST_DEVICE": "0"})
+                              extra_env={"SC_DIST_BACKEND": "gloo", "SC_TEST_DEVICE": "0", "SC_TEST_NORM": "1" if with_norm else ""})
     if rc != 0 and not os.path.exists(out):
         pytest.fail(f"rank processes failed with exit code {rc}")
     r = np.load(out)
     assert int(r["world"]) == 2 and str(r["backend"]) == "gloo"
     assert cases.rel_err(r["cauto"], g["cauto"][:nt]) < tol
     assert cases.rel_err(r["kic"], g["kic"][:nt]) < tol
+    if with_norm:
+        # norm() across ranks: each rank sums its bras against the all-gathered kets; both ranks must return
+        # the norm the single-process engine computes for the whole ensemble after the same nt steps
+        from tests.engine_cases import engine_potential, engine_propagator
+        whole = engine_propagator(g)
+        whole.run(engine_potential(g), float(g["dt"]), nt, float(g["E0"]))
+        want = whole.norm()
+        assert r["norms"].shape == (2,) and np.all(np.abs(r["norms"] - want) < 1e-10 * want), (r["norms"], want)
