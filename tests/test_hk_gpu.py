@@ -413,6 +413,58 @@ def test_constant_hessian_register_kernel_vs_oracle(D, zero_modes, diag):
     assert abs(prop.mean_energy() - float(ref.eom.en_mean)) < 1e-11 * max(1.0, abs(float(ref.eom.en_mean)))
 
 
+@pytest.mark.parametrize("D,zero_modes,diag", [(6, 0, True), (12, 6, False)])
+def test_constant_hessian_register_kernel_weak_pivots(D, zero_modes, diag):
+    """the register kernel of sc_hk_step_lin.hip eliminates in a fixed order: a state whose monodromy blocks are cyclic
+    shifts puts (almost) zero on the first pivot, so every trajectory is flagged and goes through the pivoted fix-up
+    launch; the prefactor must still agree with the oracle's LU"""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(7 * D + zero_modes)
+    n, dt = 96, 0.5
+    masses = rng.uniform(1800.0, 22000.0, D)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    om = rng.uniform(500, 3000, D) / 219474.63
+    sm = np.sqrt(masses)
+    hess0 = (Q * om ** 2) @ Q.T * np.outer(sm, sm)
+    hess0 = 0.5 * (hess0 + hess0.T)
+    pos0, grad0, nac0 = rng.normal(0, 0.1, D), rng.normal(0, 1e-3, D), rng.normal(0, 1e-2, D)
+    args = (pos0, np.float64(0.0), grad0, hess0, masses, nac0)
+    w = om * rng.uniform(0.7, 1.4, D)
+    if diag:
+        G = np.diag(w * masses)
+    else:
+        w[:zero_modes] = 0.0
+        U = np.eye(D)                                    # widths diagonal in the mass-weighted frame: L picks coordinate rows
+        G = (U * w) @ U.T * np.outer(sm, sm)
+    G = torch.from_numpy(G)
+    q0, p0 = torch.from_numpy(pos0 + rng.normal(0, 0.05, D)), torch.zeros(D)
+    ref, prop = orc.HKOracle(G, G), PR.HermanKlukPropagator(G, G, device="cuda")
+    torch.manual_seed(4)
+    ref.initial_conditions(q0, p0, G, ntraj=n)
+    prop.set_initial_conditions(q0, p0, G, ref.zi, ref.probi)
+    assert prop._pre.dprime == D - zero_modes and bool(prop._pre.diag) == diag
+    shift = np.roll(np.eye(D), 1, axis=1)
+    y = ref.y.clone()
+    for blk, mat in enumerate((shift, 0.0 * shift, 0.0 * shift, shift)):          # Mqq, Mqp, Mpq, Mpp
+        lo = 2 * D + blk * D * D
+        y[lo:lo + D * D] = torch.from_numpy(mat.reshape(-1, 1) + 1e-3 * rng.standard_normal((D * D, n)))
+    ref.y = y.clone()
+    prop.y = y.cuda()
+    pot = P.MolecularHarmonicPotential.from_arrays(*args)
+    ref_pot = orc.MolecularHarmonicOracle(*args)
+    flagged = 0
+    for _ in range(2):
+        ref.step(ref_pot, dt)
+        prop.step(pot, dt)
+        flagged += int(prop._flags[-2].item())
+        assert int(prop._flags[:-2].sum().item()) == 0
+        got, want = prop.semiclassical_prefactor().cpu().numpy(), ref.semiclassical_prefactor().numpy()
+        assert np.max(np.abs(got - want) / np.abs(want)) < 1e-9
+    assert flagged > 0, "no trajectory took the fix-up launch: the test no longer exercises it"
+
+
 @pytest.mark.parametrize("D,n", [(60, 2500), (33, 1500)])
 def test_trajectory_cursor_and_static_assignment_agree(D, n):
     """more trajectories than persistent workgroups (1024): the fast kernel hands them out through the device-side cursor
