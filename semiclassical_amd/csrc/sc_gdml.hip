@@ -39,31 +39,34 @@ __device__ __forceinline__ int pair_index(int a, int b) {      // a != b; torch.
 }
 
 struct GdmlLds {
-    double *pos, *x, *jd, *gx, *fm, *em, *wm, *ea, *grad, *P, *Qn, *Z, *dg, *stage, *red;
+    double *pos, *x, *gx, *fm, *em, *wm, *ea, *grad, *P, *Qn, *Z, *dg, *stage, *red;
     int XP;      // row stride of the MFMA operand arrays P = XJ, Qn = -e AJ, Z = w XJ - e AJ  ([GDML_CH][XP])
 };
 
-// Launch shapes.  A geometry with 3N <= 64 (10 Hessian tiles) takes four wavefronts, two geometries share a CU; a
-// larger one takes eight wavefronts.  Up to 32 atoms (21 tiles) a wavefront holds at most three 16 x 16 accumulator tiles
-// (MT = 3); 33 .. 40 atoms (36 tiles) five, 41 .. 48 atoms (45 tiles) six (round 3: the reference's predictor has no size
-// limit, gdml_predictor.py:96-250).  A chunk has one training point per wavefront (the row reductions run one point per
-// wavefront; K = 2 GDML_CH in the GEMM).
-__host__ __device__ inline int gdml_threads(int N) { return 3 * N <= 64 ? 256 : 512; }
-__host__ __device__ inline int gdml_tiles_per_wave(int N) { return N <= 32 ? 3 : (N <= 40 ? 5 : 6); }
+// Launch shapes (threads, training points per chunk, accumulator tiles per wavefront, stage buffers) by molecule size:
+//   3N <= 64 (10 Hessian tiles)    four wavefronts, CH = 4, three tiles per wavefront; two or three geometries share a CU
+//   22 .. 32 atoms                 eight wavefronts, three tiles per wavefront, CH = 8 (one training point per wavefront in
+//                                  the row reductions) while the stage fits twice, else CH = 4
+//   33 .. 40 atoms (36 tiles)      eight wavefronts, five tiles, CH = 4
+//   41 .. 48 atoms (45 tiles)      eight wavefronts, six tiles, CH = 4, ONE stage buffer (the copy of chunk k + 1 is started
+//                                  behind the last reader of chunk k and runs under the matrix-core phase only)
+// (round 3: the reference's predictor has no size limit, gdml_predictor.py:96-250).  Measured and rejected at 30 atoms: four
+// wavefronts with six tiles each and CH = 4, so that two geometries share a CU and fill each other's barrier waits (77 KB of
+// LDS each): 6.12 ms per stage launch against 5.51 ms of the eight-wavefront shape (half the training points per chunk
+// amortise the same per-chunk work, 59 spilled registers).  Every N of a row-length bucket
+// (sc_gdml_row_len) resolves to an instantiated kernel: the dispatch below matches (threads, row length, CH, NB).
+struct GdmlShape { int threads, ch, mt, nb; };
 size_t gdml_lds_doubles_ch(int N, int Dd, int ch, int nb);
-// training points per chunk: one per wavefront; four where the eight-row stage buffers do not fit twice
-// (measured at 17 atoms: eight rows on four wavefronts are no faster than four)
-inline int gdml_ch(int N) {
-    if (gdml_threads(N) == 256) return 4;
-    return gdml_lds_doubles_ch(N, N * (N - 1) / 2, 8, 2) * 8 <= 160 * 1024 ? 8 : 4;
-}
-// stage buffers: two (the copy of chunk k + 1 runs under chunk k) while they fit, one beyond (41 .. 48 atoms: the copy of
-// chunk k + 1 is started behind the last reader of chunk k and runs under the matrix-core phase only)
-// (decided for the largest molecule of the instantiation that takes N atoms, so that every N of a bucket takes the same kernel)
 extern "C" int sc_gdml_row_len(int32_t n_atoms);
-inline int gdml_nb(int N) {
-    const int nmax = sc_gdml_row_len(N) > 0 ? sc_gdml_row_len(N) : N;
-    return gdml_lds_doubles_ch(nmax, nmax * (nmax - 1) / 2, gdml_ch(nmax), 2) * 8 <= 160 * 1024 ? 2 : 1;
+inline GdmlShape gdml_shape(int N) {
+    const int Dd = N * (N - 1) / 2;
+    const size_t cu = 160 * 1024;
+    if (3 * N <= 64) return {256, 4, 3, 2};
+    if (N <= 32) {
+        return {512, gdml_lds_doubles_ch(N, Dd, 8, 2) * 8 <= cu ? 8 : 4, 3, 2};
+    }
+    if (N <= 40) return {512, 4, 5, 2};
+    return {512, 4, 6, 1};
 }
 
 // row stride of the operand arrays: 16 T (+16) doubles with stride = 16 mod 32, so that the four rows an MFMA operand
@@ -79,7 +82,6 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int GDML_CH) {
     L.red = f;  f += 32;
     L.pos = f;  f += 3 * N;
     L.x = f;    f += Dd;
-    L.jd = f;   f += 3 * Dd;
     L.gx = f;   f += Dd;
     L.fm = f;   f += GDML_CH;
     L.em = f;   f += GDML_CH;
@@ -97,10 +99,10 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int GDML_CH) {
 }
 
 size_t gdml_lds_doubles_ch(int N, int Dd, int GDML_CH, int nb) {
-    return 32 + 3 * N + 5 * (size_t)Dd + 4 * GDML_CH + 3 * N + (N & 1) + 9 * N + (N & 1) + 3 * (size_t)GDML_CH * gdml_xp(N) +
+    return 32 + 3 * N + 2 * (size_t)Dd + 4 * GDML_CH + 3 * N + (N & 1) + 9 * N + (N & 1) + 3 * (size_t)GDML_CH * gdml_xp(N) +
            (size_t)nb * 2 * (size_t)GDML_CH * Dd + 1;       // + 1: alignment pad of the stage
 }
-size_t gdml_lds_doubles(int N, int Dd) { return gdml_lds_doubles_ch(N, Dd, gdml_ch(N), gdml_nb(N)); }
+size_t gdml_lds_doubles(int N, int Dd) { const GdmlShape sh = gdml_shape(N); return gdml_lds_doubles_ch(N, Dd, sh.ch, sh.nb); }
 
 // V (without origin), grad[3N] (LDS, L.grad) and hess[3N][3N] (global, row-major) at the geometry in L.pos.
 // Every thread returns the energy.  256 threads.
@@ -151,12 +153,13 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         const int k = G.pair_k[d], l = G.pair_l[d];
         const double dx = L.pos[3 * k] - L.pos[3 * l], dy = L.pos[3 * k + 1] - L.pos[3 * l + 1],
                      dz = L.pos[3 * k + 2] - L.pos[3 * l + 2];
-        const double x = 1.0 / sqrt(dx * dx + dy * dy + dz * dz), x3 = x * x * x;
-        L.x[d] = x;
-        L.jd[3 * d] = -x3 * dx; L.jd[3 * d + 1] = -x3 * dy; L.jd[3 * d + 2] = -x3 * dz;
+        L.x[d] = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
     }
     for (int e = tid; e < 3 * GDML_CH * L.XP; e += nth) L.P[e] = 0.0;       // P, Qn, Z are contiguous: padding columns stay 0
     __syncthreads();
+    // Jacobian coefficient of pair (a, c) on atom a, component u: d x_(a,c) / d r_a[u] = -x^3 (r_a - r_c)[u] (computed where it
+    // is needed -- once per geometry -- instead of kept in LDS: 3 Dd doubles less per workgroup)
+    auto jac = [&](double x3, int a, int c, int u) { return -x3 * (L.pos[3 * a + u] - L.pos[3 * c + u]); };
     // accumulator tiles of the rank-M sums on the matrix cores.  Tile t = c (c + 1) / 2 + r, r <= c, of the upper triangle
     // belongs to wavefront t % nw; accumulator layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 reg.
     typedef double d4 __attribute__((ext_vector_type(4)));
@@ -192,10 +195,10 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         const int c = QN * fm_q + cc;
         const bool ok = c < N && c != fm_at;
         const int d = ok ? pair_index(fm_at, c) : 0;
-        const double xq = ok ? L.x[d] : 0.0;
+        const double xq = ok ? L.x[d] : 0.0, x3 = xq * xq * xq;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            const double j = ok ? ((fm_at > c) ? L.jd[3 * d + u] : -L.jd[3 * d + u]) : 0.0;
+            const double j = ok ? jac(x3, fm_at, c, u) : 0.0;
             coef[u][cc] = j;
             base[u] = fma(j, xq, base[u]);
         }
@@ -319,8 +322,10 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
             if (d < Dd) {
                 for (int mm = 0; mm < mc; ++mm) {
                     const double t = fma(L.fm[mm], sal[mm * Dd + d], -L.ea[mm] * (xown[j] - sxs[mm * Dd + d]));
-                    const double sn = gacc[j] + t;
-                    gcomp[j] += fabs(gacc[j]) >= fabs(t) ? (gacc[j] - sn) + t : (t - sn) + gacc[j];
+                    // the exact rounding error of the addition (branch-free two-sum: the same value as the magnitude-ordered
+                    // form, without the compare and selects)
+                    const double sn = gacc[j] + t, bb = sn - gacc[j];
+                    gcomp[j] += (gacc[j] - (sn - bb)) + (t - bb);
                     gacc[j] = sn;
                 }
             }
@@ -346,25 +351,31 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         //     first, then the MFMAs of the tiles run interleaved (one block, no wait between the products)
 #ifndef GDML_ABLATE_MFMA
         {
-            constexpr int KS = GDML_CH / 4;
-            double oa[GDML_MAX_TILES][KS][2], ob[GDML_MAX_TILES][KS][2];
+            // tiles in groups of three: the operands of a group are requested first, then its MFMAs run interleaved
+            constexpr int KS = GDML_CH / 4, TG = GDML_MAX_TILES > 3 ? 3 : GDML_MAX_TILES;
 #pragma unroll
-            for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
-                const double *ar = L.P + rg * XP + 16 * tr_[sl] + li, *bc = L.Z + rg * XP + 16 * tc_[sl] + li;
-                const double *aq = L.Qn + rg * XP + 16 * tr_[sl] + li, *bp = L.P + rg * XP + 16 * tc_[sl] + li;
+            for (int s0 = 0; s0 < GDML_MAX_TILES; s0 += TG) {
+                double oa[TG][KS][2], ob[TG][KS][2];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    oa[sl][ks][0] = ar[4 * ks * XP]; ob[sl][ks][0] = bc[4 * ks * XP];
-                    oa[sl][ks][1] = aq[4 * ks * XP]; ob[sl][ks][1] = bp[4 * ks * XP];
+                for (int g = 0; g < TG; ++g) {
+                    const int sl = s0 + g < GDML_MAX_TILES ? s0 + g : GDML_MAX_TILES - 1;
+                    const double *ar = L.P + rg * XP + 16 * tr_[sl] + li, *bc = L.Z + rg * XP + 16 * tc_[sl] + li;
+                    const double *aq = L.Qn + rg * XP + 16 * tr_[sl] + li, *bp = L.P + rg * XP + 16 * tc_[sl] + li;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        oa[g][ks][0] = ar[4 * ks * XP]; ob[g][ks][0] = bc[4 * ks * XP];
+                        oa[g][ks][1] = aq[4 * ks * XP]; ob[g][ks][1] = bp[4 * ks * XP];
+                    }
                 }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int w = 0; w < 2; ++w)
+#pragma unroll
+                        for (int g = 0; g < TG; ++g)
+                            if (s0 + g < GDML_MAX_TILES)
+                                acc[s0 + g] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[g][ks][w], ob[g][ks][w], acc[s0 + g], 0, 0, 0);
             }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int w = 0; w < 2; ++w)
-#pragma unroll
-                    for (int sl = 0; sl < GDML_MAX_TILES; ++sl)
-                        acc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[sl][ks][w], ob[sl][ks][w], acc[sl], 0, 0, 0);
         }
 #endif
     }
@@ -382,8 +393,8 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         for (int b = 0; b < N; ++b) {
             if (b == a) continue;
             const int d = pair_index(a, b);
-            const double j = L.jd[3 * d + u] * L.gx[d];
-            g += (a > b) ? j : -j;
+            const double x = L.x[d];
+            g += jac(x * x * x, a, b, u) * L.gx[d];
         }
         L.grad[xi] = g * G.std;
     }
@@ -394,9 +405,10 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         for (int c = 0; c < N; ++c) {
             if (c == a) continue;
             const int d = pair_index(a, c);
-            const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x, ix3 = -1.0 / x3;
-            const double ju = L.jd[3 * d + u], jv = L.jd[3 * d + v];
-            sum += -S * ju * jv + 3.0 * g * x5 * (ju * ix3) * (jv * ix3) - (u == v ? g * x3 : 0.0);
+            // d2x / dr_u dr_v = 3 x^5 du dv - delta_uv x^3 with the displacement du = (r_a - r_c)[u] = jd[u] / (-x^3)
+            const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x;
+            const double du = L.pos[3 * a + u] - L.pos[3 * c + u], dv = L.pos[3 * a + v] - L.pos[3 * c + v];
+            sum += -S * (x3 * du) * (x3 * dv) + 3.0 * g * x5 * du * dv - (u == v ? g * x3 : 0.0);
         }
         L.dg[e] = sum;
     }
@@ -414,9 +426,9 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
             if (a == b) fin = L.dg[9 * a + 3 * u + v];
             else {
                 const int d = pair_index(a, b);
-                const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x, ix3 = -1.0 / x3;
-                const double ju = L.jd[3 * d + u], jv = L.jd[3 * d + v];
-                fin = S * ju * jv - (3.0 * g * x5 * (ju * ix3) * (jv * ix3) - (u == v ? g * x3 : 0.0));
+                const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x;
+                const double du = L.pos[3 * a + u] - L.pos[3 * b + u], dv = L.pos[3 * a + v] - L.pos[3 * b + v];
+                fin = S * (x3 * du) * (x3 * dv) - (3.0 * g * x5 * du * dv - (u == v ? g * x3 : 0.0));
             }
             const double val = (acc[sl][qq] + fin) * G.std;
             hess[(size_t)xr * X + y] = val;
@@ -522,7 +534,8 @@ int check_model(const sc_gdml_model *g, const char *who) {
         return sc_fail(SC_ERR_UNSUPPORTED, "%s: model (N=%d) needs more than 160 KiB of LDS", who, g->n_atoms);
     {
         const int T = (3 * g->n_atoms + 15) / 16;
-        if (T * (T + 1) / 2 > gdml_tiles_per_wave(g->n_atoms) * (gdml_threads(g->n_atoms) / 64))
+        const GdmlShape sh = gdml_shape(g->n_atoms);
+        if (T * (T + 1) / 2 > sh.mt * (sh.threads / 64))
             return sc_fail(SC_ERR_UNSUPPORTED, "%s: %d atoms need more Hessian tiles than the kernel holds", who, g->n_atoms);
     }
     return SC_OK;
@@ -547,7 +560,8 @@ extern "C" int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, 
         hipLaunchKernelGGL((gdml_eval_kernel<TH_, HN_, CH_, MT_, NB_>), dim3(grid), dim3(TH_), lds, (hipStream_t)stream, a);         \
         launched = true;                                                                                                   \
     }
-    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms), nb = gdml_nb(g->n_atoms);
+    const GdmlShape sh = gdml_shape(g->n_atoms);
+    const int threads = sh.threads, row_len = sc_gdml_row_len(g->n_atoms), ch = sh.ch, nb = sh.nb;
     bool launched = false;
     SC_GDML_EVAL(256, 4, 4, 3, 2) SC_GDML_EVAL(256, 8, 4, 3, 2) SC_GDML_EVAL(256, 10, 4, 3, 2) SC_GDML_EVAL(256, 12, 4, 3, 2)
     SC_GDML_EVAL(512, 12, 8, 3, 2) SC_GDML_EVAL(512, 16, 8, 3, 2) SC_GDML_EVAL(512, 16, 4, 3, 2)
@@ -579,7 +593,8 @@ extern "C" int sc_gdml_stage(const sc_gdml_model *g, const sc_state *st, const s
         hipLaunchKernelGGL((gdml_stage_kernel<TH_, HN_, CH_, MT_, NB_>), dim3(sc_dense_grid(st->n)), dim3(TH_), lds, (hipStream_t)stream, a); \
         launched = true;                                                                                                   \
     }
-    const int threads = gdml_threads(g->n_atoms), row_len = sc_gdml_row_len(g->n_atoms), ch = gdml_ch(g->n_atoms), nb = gdml_nb(g->n_atoms);
+    const GdmlShape sh = gdml_shape(g->n_atoms);
+    const int threads = sh.threads, row_len = sc_gdml_row_len(g->n_atoms), ch = sh.ch, nb = sh.nb;
     bool launched = false;
     SC_GDML_STAGE(256, 4, 4, 3, 2) SC_GDML_STAGE(256, 8, 4, 3, 2) SC_GDML_STAGE(256, 10, 4, 3, 2) SC_GDML_STAGE(256, 12, 4, 3, 2)
     SC_GDML_STAGE(512, 12, 8, 3, 2) SC_GDML_STAGE(512, 16, 8, 3, 2) SC_GDML_STAGE(512, 16, 4, 3, 2)
