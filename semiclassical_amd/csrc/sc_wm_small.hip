@@ -37,10 +37,15 @@ namespace {
 template <int D, int DP>
 struct WmSmallLayout {
     static constexpr int E = 2 * DP, EP = E | 1;
-    static constexpr int n_const = 5 * 16 * D        // rows of Gt, G0, Cqq, S, iGi0, zero padded to 16 lanes
-                                   + 16 * D          // UT[i][a] = U[a][i], zero for i >= d'
-                                   + 3 * 16 * DP     // rows of U, Re Bq'[:, :d'] = Gamma_i U, Im Bq'[:, d':] = -U / hbar
-                                   + 2 * 16 * E      // rows of Cst' / s (complex), zero for r >= e
+    // row pitches of the per-lane constants: lane r reads ITS row, so the pitch decides the banks the 16 lanes of a row meet
+    // on (rows 8 D bytes apart: lanes r and r + 8 on one bank at D = 12; measured SQ_LDS_BANK_CONFLICT = 61 % of the LDS cycles).
+    // One element more per row spreads them (as in sc_hk_step_lin.hip).
+    static constexpr int PD = D + 1, PDP = DP + 1, PE = E + 1;
+    static constexpr int n_const = 5 * 16 * PD       // rows of Gt, G0, Cqq, S, iGi0, zero padded to 16 lanes
+                                   + 16 * PD         // UT[i][a] = U[a][i], zero for i >= d'
+                                   + 3 * 16 * PDP    // rows of U, Re Bq'[:, :d'] = Gamma_i U, Im Bq'[:, d':] = -U / hbar
+                                   + (3 * 16 * PDP & 1)   // keeps the complex rows below 16-byte aligned
+                                   + 2 * 16 * PE     // rows of Cst' / s (complex), zero for r >= e
                                    + 8 * 16;         // q0, p0, n1, s_n1, w_n1, crow = Cqq n1, 2 spare
     static constexpr int PB = 2 * E + 2;             // doubles per lane of the parked BQ' row (pitch: 16-byte aligned, odd in 16-byte units)
     static constexpr int xt = D * EP + 16;           // transposition buffer (+16: lanes beyond the matrix read, never use)
@@ -91,16 +96,17 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     const double ihb = 1.0 / SC_HBAR, sA = W.inv_scale_a;
 
     double *ls = (double *)smem2;
-    double *sGt = ls;   ls += 16 * D;
-    double *sG0 = ls;   ls += 16 * D;
-    double *sCqq = ls;  ls += 16 * D;
-    double *sS = ls;    ls += 16 * D;
-    double *siG = ls;   ls += 16 * D;
-    double *sUT = ls;   ls += 16 * D;
-    double *sU = ls;    ls += 16 * DP;
-    double *sBr = ls;   ls += 16 * DP;
-    double *sBi = ls;   ls += 16 * DP;
-    double *sCst = ls;  ls += 2 * 16 * E;
+    constexpr int PD = L::PD, PDP = L::PDP, PE = L::PE;
+    double *sGt = ls;   ls += 16 * PD;
+    double *sG0 = ls;   ls += 16 * PD;
+    double *sCqq = ls;  ls += 16 * PD;
+    double *sS = ls;    ls += 16 * PD;
+    double *siG = ls;   ls += 16 * PD;
+    double *sUT = ls;   ls += 16 * PD;
+    double *sU = ls;    ls += 16 * PDP;
+    double *sBr = ls;   ls += 16 * PDP;
+    double *sBi = ls;   ls += 16 * PDP + (3 * 16 * PDP & 1);
+    double *sCst = ls;  ls += 2 * 16 * PE;
     double *cvec = ls;  ls += 8 * 16;            // [q0 | p0 | n1 | s_n1 | w_n1 | crow | - | -][16]
     double *xall = ls;
 
@@ -108,24 +114,26 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
     for (int e = tid; e < 16 * D; e += 256) {
         const int i = e / D, b = e - i * D;
         const bool in = i < D;
-        sGt[e] = in ? W.Gt[i * D + b] : 0.0;
-        sG0[e] = in ? W.G0[i * D + b] : 0.0;
-        sCqq[e] = in ? W.Cqq[i * D + b] : 0.0;
-        sS[e] = in ? W.S[i * D + b] : 0.0;
-        siG[e] = in ? W.iGi0[i * D + b] : 0.0;
-        sUT[e] = i < DP ? W.U[b * DP + i] : 0.0;
+        const int o = i * PD + b;
+        sGt[o] = in ? W.Gt[i * D + b] : 0.0;
+        sG0[o] = in ? W.G0[i * D + b] : 0.0;
+        sCqq[o] = in ? W.Cqq[i * D + b] : 0.0;
+        sS[o] = in ? W.S[i * D + b] : 0.0;
+        siG[o] = in ? W.iGi0[i * D + b] : 0.0;
+        sUT[o] = i < DP ? W.U[b * DP + i] : 0.0;
     }
     for (int e = tid; e < 16 * DP; e += 256) {
         const int i = e / DP, k = e - i * DP;
         const bool in = i < D;
-        sU[e] = in ? W.U[i * DP + k] : 0.0;
-        sBr[e] = in ? W.Bq[2 * (i * E + k)] : 0.0;                   // Re Bq'[i][k]      = (Gamma_i U)[i][k]
-        sBi[e] = in ? W.Bq[2 * (i * E + DP + k) + 1] : 0.0;          // Im Bq'[i][d' + k] = -U[i][k] / hbar
+        const int o = i * PDP + k;
+        sU[o] = in ? W.U[i * DP + k] : 0.0;
+        sBr[o] = in ? W.Bq[2 * (i * E + k)] : 0.0;                   // Re Bq'[i][k]      = (Gamma_i U)[i][k]
+        sBi[o] = in ? W.Bq[2 * (i * E + DP + k) + 1] : 0.0;          // Im Bq'[i][d' + k] = -U[i][k] / hbar
     }
     for (int e = tid; e < 16 * E; e += 256) {
         const int i = e / E, j = e - i * E;
-        sCst[2 * e] = i < E ? W.Cst[2 * (i * E + j)] * sA : 0.0;
-        sCst[2 * e + 1] = i < E ? W.Cst[2 * (i * E + j) + 1] * sA : 0.0;
+        sCst[2 * (i * PE + j)] = i < E ? W.Cst[2 * (i * E + j)] * sA : 0.0;
+        sCst[2 * (i * PE + j) + 1] = i < E ? W.Cst[2 * (i * E + j) + 1] * sA : 0.0;
     }
     if (tid < 16) {
         const bool in = tid < D, nac = in && A.has_nac;
@@ -150,10 +158,10 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
         // the per-lane rows of the constants are read from LDS where they are used, never kept across phases
         int lofs = 0;
         asm volatile("" : "+v"(lofs));
-        const double *cGt = sGt + lofs + r * D, *cG0 = sG0 + lofs + r * D, *cCqq = sCqq + lofs + r * D, *cS = sS + lofs + r * D;
-        const double *ciG = siG + lofs + r * D, *cUT = sUT + lofs + r * D, *cU = sU + lofs + r * DP, *cBr = sBr + lofs + r * DP;
-        const double *cBi = sBi + lofs + r * DP;
-        const cplx *cCst = (const cplx *)(sCst + lofs) + r * E;
+        const double *cGt = sGt + lofs + r * PD, *cG0 = sG0 + lofs + r * PD, *cCqq = sCqq + lofs + r * PD, *cS = sS + lofs + r * PD;
+        const double *ciG = siG + lofs + r * PD, *cUT = sUT + lofs + r * PD, *cU = sU + lofs + r * PDP, *cBr = sBr + lofs + r * PDP;
+        const double *cBi = sBi + lofs + r * PDP;
+        const cplx *cCst = (const cplx *)(sCst + lofs) + r * PE;
         const double *cv = cvec + lofs;
 
         // ---- rows of the monodromy blocks; Mq' = [Mqq U, Mqp U], Mp' = [Mpq U, Mpp U] (row r) ----
