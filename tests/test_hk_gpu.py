@@ -465,6 +465,46 @@ def test_constant_hessian_register_kernel_weak_pivots(D, zero_modes, diag):
     assert flagged > 0, "no trajectory took the fix-up launch: the test no longer exercises it"
 
 
+def test_constant_hessian_register_kernel_unaligned_state_takes_general_kernel():
+    """the row prefetch of sc_hk_step_lin.hip moves 16-byte units: a caller of the C-ABI whose state arrays are only 8-byte
+    aligned must still get the right answer (the dispatcher hands such a state to the general kernel)"""
+    from semiclassical_amd import potentials as P, propagators as PR
+    from semiclassical_amd._lib import lib, check, ptr
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(11)
+    D, n, dt = 6, 200, 3.0
+    masses = rng.uniform(1800.0, 22000.0, D)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    om = rng.uniform(500, 3000, D) / 219474.63
+    sm = np.sqrt(masses)
+    hess0 = (Q * om ** 2) @ Q.T * np.outer(sm, sm)
+    hess0 = 0.5 * (hess0 + hess0.T)
+    pos0 = rng.normal(0, 0.1, D)
+    args = (pos0, np.float64(0.0), rng.normal(0, 1e-3, D), hess0, masses, rng.normal(0, 1e-2, D))
+    G = torch.from_numpy(np.diag(om * masses))
+    q0 = torch.from_numpy(pos0 + rng.normal(0, 0.05, D))
+    pot = P.MolecularHarmonicPotential.from_arrays(*args)
+    a, b = (PR.HermanKlukPropagator(G, G, device="cuda") for _ in range(2))
+    for prop in (a, b):
+        prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(2))
+    for _ in range(3):
+        a.step(pot, dt)
+    desc = b._potential_descriptor(pot, dt)
+    st = type(b._state).from_buffer_copy(b._state)
+    shifted = torch.zeros(n + 1, device="cuda")
+    act = shifted[1:]                                 # 8 bytes off a 16-byte boundary
+    act.copy_(b._act)
+    assert act.data_ptr() % 16 == 8
+    st.act = ptr(act)
+    for _ in range(3):
+        check(lib.sc_hk_step(desc, st, b._hk, dt, 0, ptr(b._epart), b._stream()))
+    torch.cuda.synchronize()
+    for x, y in ((a._qp, b._qp), (a._act, act), (a._mono, b._mono)):
+        assert cases.rel_err(x.cpu(), y.cpu()) < 1e-12
+    assert cases.rel_err(torch.view_as_real(a._c2).cpu(), torch.view_as_real(b._c2).cpu()) < 1e-11
+    assert torch.equal(a._sgn, b._sgn)
+
+
 @pytest.mark.parametrize("D,n", [(60, 2500), (33, 1500)])
 def test_trajectory_cursor_and_static_assignment_agree(D, n):
     """more trajectories than persistent workgroups (1024): the fast kernel hands them out through the device-side cursor
