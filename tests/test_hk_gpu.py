@@ -465,14 +465,16 @@ def test_constant_hessian_register_kernel_weak_pivots(D, zero_modes, diag):
     assert flagged > 0, "no trajectory took the fix-up launch: the test no longer exercises it"
 
 
-def test_constant_hessian_register_kernel_unaligned_state_takes_general_kernel():
+@pytest.mark.parametrize("D,n", [(6, 200), (12, 17), (12, 2 * 8192 + 37)])
+def test_constant_hessian_register_kernel_unaligned_state_takes_general_kernel(D, n):
     """the row prefetch of sc_hk_step_lin.hip moves 16-byte units: a caller of the C-ABI whose state arrays are only 8-byte
-    aligned must still get the right answer (the dispatcher hands such a state to the general kernel)"""
+    aligned must still get the right answer (the dispatcher hands such a state to the general kernel).  The large batch
+    gives every persistent workgroup several passes (rows requested one pass ahead) and a ragged last one."""
     from semiclassical_amd import potentials as P, propagators as PR
     from semiclassical_amd._lib import lib, check, ptr
     torch.set_default_dtype(torch.float64)
     rng = np.random.default_rng(11)
-    D, n, dt = 6, 200, 3.0
+    dt = 3.0
     masses = rng.uniform(1800.0, 22000.0, D)
     Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
     om = rng.uniform(500, 3000, D) / 219474.63
