@@ -219,6 +219,24 @@ def config3(dev, n, steps):
                                  "frac": algorithmic_bytes_per_traj_step(D) * n / (hk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
+def config3_hk(dev, n, steps):
+    """the same methylium model with the HK propagator (the reference's own methylium_AH example runs both): the constant-Hessian
+    step kernel plus the correlation kernel for DENSE, rank-deficient width matrices"""
+    from semiclassical_amd import potentials as P, propagators as PR
+    g = _load("hk_methylium")
+    pot = P.MolecularHarmonicPotential.from_arrays(g["pos0"], g["energy0"], g["grad0"], g["hess0"], g["masses"], g["nac0"],
+                                                   origin=float(g["origin"]))
+    Gi = _T(g["Gamma_i"])
+    prop = PR.HermanKlukPropagator(Gi, Gi, device=dev)
+    prop.initial_conditions(_T(g["q0"]), _T(g["p0"]), _T(g["Gamma_0"]), ntraj=n, generator=torch.Generator().manual_seed(7))
+    dt, E0 = float(g["dt"]), float(g["E0"])
+    wall = _timed_loop(prop, pot, dt, E0, steps, dev)
+    k = _kernel_ms(prop, pot, dt, E0, steps, dev)
+    return {"workload": f"harmonic methylium D=12 d'=6, HK, n={n} (not a BASELINE configuration: the HK half of the reference's methylium example)",
+            "n": n, "steps": steps, "ms_per_step": wall / steps * 1e3, "value": n * steps / wall, "unit": "trajectory-steps/s",
+            "kernels_ms": {kk: vv for kk, vv in k.items()}}
+
+
 def config5(dev, n, steps):
     """configs[4]: sGDML potential, 30 atoms (synthetic model of SURVEY.md section 8d: D = 90, Dd = 435, M = 200), HK"""
     from semiclassical_amd import propagators as PR
@@ -268,7 +286,7 @@ def config5(dev, n, steps):
 def other_configs(dev):
     out = {}
     for key, fn, args in (("config1_n1000", config1, (1000, 100)), ("config1_n100000", config1, (100000, 50)),
-                          ("config3_wm_methylium", config3, (100000, 30)),
+                          ("config3_wm_methylium", config3, (100000, 30)), ("methylium_hk", config3_hk, (100000, 30)),
                           ("config5_gdml30_share", config5, (1250, 5)), ("config5_gdml30_n10000", config5, (10000, 3))):
         try:
             out[key] = fn(dev, *args)
@@ -326,7 +344,7 @@ def parse_args(argv=None):
                     help="trajectories of the whole job, sharded over the GPUs (default at --gpus 8: 10^6 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration lines and the 2000-step run")
-    ap.add_argument("--config", choices=["1", "3", "5"], default=None,
+    ap.add_argument("--config", choices=["1", "3", "3hk", "5"], default=None,
                     help="run ONLY that BASELINE configuration's side measurement (for one rocprofv3 summary per configuration: "
                          "1 = 5-mode AS at n = 1e5, 3 = methylium WM at n = 1e5, 5 = 30-atom sGDML at n = 1e4) and print its JSON")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -346,7 +364,7 @@ def main():
     torch.set_default_dtype(torch.float64)
     if args.config is not None:
         dev = torch.device("cuda", 0)
-        fn, fargs = {"1": (config1, (100000, 50)), "3": (config3, (100000, 30)), "5": (config5, (10000, 3))}[args.config]
+        fn, fargs = {"1": (config1, (100000, 50)), "3": (config3, (100000, 30)), "3hk": (config3_hk, (100000, 30)), "5": (config5, (10000, 3))}[args.config]
         print(json.dumps({f"config{args.config}": fn(dev, *fargs)}), flush=True)
         return
     from semiclassical_amd import distributed as D

@@ -7,6 +7,7 @@
 //   Monte-Carlo weight 1/(n probi (2 pi hbar)^D)  semiclassical/propagators.py:837
 //   nacQ, nacq, k_ic                              semiclassical/propagators.py:886-909
 #include "sc_common.h"
+#include "sc_row16.h"
 
 namespace {
 
@@ -185,6 +186,96 @@ __global__ __launch_bounds__(256) void hk_correlate_kernel(CorrArgs A) {
     }
 }
 
+// Dense (or rank-deficient) width matrices, D <= 16 -- methylium with the reference's Cartesian widths: ONE trajectory per
+// 16-lane DPP row.  Lane a keeps row a of the overlap's matrices A, B, C in registers; y_a = sum_b A_ab dq_b takes the
+// displacement of lane b inside the multiply-add (v_fmac_f64_dpp row_newbcast, sc_row16.h), the six sums over the modes
+// are fused broadcast multiply-adds with 1.0.  A wavefront takes 64 consecutive trajectories, row g the 16 from
+// base + 16 g one after the other; lane j of a row parks the sums of the row's j-th trajectory, so that afterwards all 64
+// lanes evaluate the scalar tails (complex exp, sqrt, phase, weight) side by side.  Replaces, for these shapes, the branch
+// of hk_correlate_kernel that runs one trajectory per wavefront pass with 12 of 64 lanes and re-reads A, B, C from memory
+// per trajectory (0.67 ms per step at n = 1e5, three times the step kernel).
+__global__ __launch_bounds__(256) void hk_correlate_rows16_kernel(CorrArgs A) {
+    __shared__ double wsum[4][4];
+    const int D = A.st.dim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = tid & 15, g = (tid >> 4) & 3;
+    const bool own = r < D, nac = A.has_nac != 0;
+    double rowA[16], rowB[16], rowC[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const bool in = own && b < D;
+        rowA[b] = in ? A.oc.A[r * D + b] : 0.0; rowB[b] = in ? A.oc.B[r * D + b] : 0.0; rowC[b] = in ? A.oc.C[r * D + b] : 0.0;
+    }
+    const double qk = own ? A.oc.qk[r] : 0.0, pk = own ? A.oc.pk[r] : 0.0;
+    const double nq0 = (own && nac) ? A.nc.q0[r] : 0.0, np0 = (own && nac) ? A.nc.p0[r] : 0.0;
+    const double nrn = (own && nac) ? A.nc.rn[r] : 0.0, ngn = (own && nac) ? A.nc.gn[r] : 0.0;
+    double one = 1.0;
+    asm volatile("" : "+v"(one));
+    double acc[4] = {0, 0, 0, 0};
+    const int64_t n = A.st.n, nbatch = (n + 63) / 64;
+    for (int64_t batch = (int64_t)blockIdx.x * 4 + wave; batch < nbatch; batch += (int64_t)gridDim.x * 4) {
+        const int64_t base = batch * 64 + 16 * g;
+        double m[6] = {0, 0, 0, 0, 0, 0};
+        auto fetch = [&](int j, double &q, double &p) {
+            const int64_t t = base + j;
+            const bool ok = own && t < n;
+            q = ok ? A.st.qp[t * 2 * D + r] : qk;
+            p = ok ? A.st.qp[t * 2 * D + D + r] : pk;
+        };
+        double qn, pn;
+        fetch(0, qn, pn);
+        for (int j = 0; j < 16; ++j) {
+            const double q = qn, p = pn;
+            if (j + 1 < 16) fetch(j + 1, qn, pn);              // requested before the dependent chains of trajectory j
+            double dq = qk - q, dpp = pk - p;
+            double ya = 0.0, yb = 0.0, yc = 0.0;
+            dpp_guard(dq, dpp);
+            sfor<0, 16>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                if (b < D) { fmac_bc<b>(ya, dq, rowA[b]); fmac_bc<b>(yb, dpp, rowB[b]); fmac_bc<b>(yc, dpp, rowC[b]); }
+            });
+            double t[6] = {dq * ya, dpp * yb, pk * dq, dq * yc, (nq0 - q) * nrn, (p - np0) * ngn}, s[6] = {0, 0, 0, 0, 0, 0};
+            dpp_guard(t);
+            sfor<0, 16>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if (k < D) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) fmac_bc<k>(s[i], t[i], one);
+                }
+            });
+            if (r == j) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) m[i] = s[i];
+            }
+        }
+        const int64_t tr = batch * 64 + lane;                  // lane (g, r) parked trajectory base + r
+        if (tr < n) {
+            const cplx vt = overlap_value(A.oc, m[0], m[1], m[2], m[3]);
+            const cplx c = c_scale(c_sqrt(((const cplx *)A.st.c2)[tr]), A.st.sgn[tr]);
+            const cplx ph = c_exp(c_make(0.0, A.st.act[tr] / SC_HBAR));
+            const double w = 1.0 / (A.mc_norm * A.probi[tr]);
+            cplx cq = c_mul(c_mul(c_conj(vt), ((const cplx *)A.vi)[tr]), c_mul(c, ph));
+            cq = c_scale(cq, w);
+            acc[0] += cq.x; acc[1] += cq.y;
+            if (A.cq_out) ((cplx *)A.cq_out)[tr] = cq;
+            if (nac) {
+                const cplx nacQ = c_make(A.nc.n2 + m[4], -(A.nc.p0n1 + m[5]) / SC_HBAR);
+                cplx kq = c_mul(c_mul(nacQ, ((const cplx *)A.nacq)[tr]), cq);
+                kq = c_scale(kq, 1.0 / (SC_HBAR * SC_HBAR));
+                acc[2] += kq.x; acc[3] += kq.y;
+                if (A.kq_out) ((cplx *)A.kq_out)[tr] = kq;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);      // fixed order: deterministic
+    if (lane == 0) { for (int i = 0; i < 4; ++i) wsum[wave][i] = acc[i]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double sum = 0;
+        for (int w = 0; w < 4; ++w) sum += wsum[w][threadIdx.x];
+        A.partials[(size_t)blockIdx.x * 4 + threadIdx.x] = sum;
+    }
+}
+
 struct ReduceArgs {
     const double *cpart;
     int ncorr;
@@ -301,8 +392,11 @@ extern "C" int sc_hk_correlate(const sc_state *st, const sc_overlap_consts *ovl_
     if (nc) a.nc = *nc; else a.nc = sc_nac_consts{};
     a.vi = vi; a.probi = probi; a.nacq = nacq; a.mc_norm = mc_norm;
     a.cq_out = cq_out; a.kq_out = kq_out; a.partials = partials;
-    hipLaunchKernelGGL(hk_correlate_kernel, dim3(sc_correlate_grid(st->n, st->dim)), dim3(256),
-                       wave_scratch_bytes(st->dim, ovl_t0->diag), (hipStream_t)stream, a);
+    if (!ovl_t0->diag && st->dim <= 16)
+        hipLaunchKernelGGL(hk_correlate_rows16_kernel, dim3(sc_correlate_grid(st->n, st->dim)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(hk_correlate_kernel, dim3(sc_correlate_grid(st->n, st->dim)), dim3(256),
+                           wave_scratch_bytes(st->dim, ovl_t0->diag), (hipStream_t)stream, a);
     return sc_check_launch("sc_hk_correlate");
 }
 

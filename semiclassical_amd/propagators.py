@@ -458,10 +458,11 @@ class HermanKlukPropagator(object):
         """per-trajectory terms + their sums for the current state into the 5-double slot at `slot_ptr`"""
         s = self._stream()
         nac = self._nac
-        check(lib.sc_hk_correlate(self._state, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
-                                  ptr(self._nacq) if nac is not None else None, self._mc_norm(),
-                                  ptr(self._cq) if per_trajectory else None,
-                                  ptr(self._kq) if per_trajectory else None, ptr(self._cpart), s))
+        with self._timed("hk_correlate"):
+            check(lib.sc_hk_correlate(self._state, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
+                                      ptr(self._nacq) if nac is not None else None, self._mc_norm(),
+                                      ptr(self._cq) if per_trajectory else None,
+                                      ptr(self._kq) if per_trajectory else None, ptr(self._cpart), s))
         self._reduce_into(self._cpart, self._gcorr, slot_ptr, cursor)
 
     def _correlate_current(self, need_nac):
