@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 dst=gpurun_out/profiles_$tag       # summaries (small): gpurun merges gpurun_out/ back, copy them to profiles/ afterwards
 mkdir -p $out $dst
-for c in 1 3 5; do
+for c in 1 3 3hk 5; do
     rocprofv3 --kernel-trace --stats -d $out/c$c -o run -- python3 bench.py --config $c > $out/c$c.log 2>&1
     python tools/kernel_stats.py $out/c$c $dst/${tag}_config${c}_kernel_stats.csv \
         "rocprofv3 --kernel-trace --stats -- python3 bench.py --config $c (ONE configuration per run: averages are not mixed over batch sizes)" > /dev/null
