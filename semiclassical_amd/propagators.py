@@ -542,11 +542,16 @@ class HermanKlukPropagator(object):
         self._sync_dense_mono(leave_diagonal=True)
         self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
         nslots = lib.sc_hk_run_slots(self.ntraj, self.dim)
-        partials = torch.empty((nt, nslots, 5), dtype=F64, device=self.device)
+        # per-step partial sums of every wavefront: 40 nslots bytes per step; long runs go in launches of <= 4096 steps
+        # (<= 0.7 GB of partials, reused: the launches are ordered on the stream), the state stays on the device in between
+        chunk = min(nt, 4096)
+        partials = torch.empty((chunk, nslots, 5), dtype=F64, device=self.device)
         nac = self._nac
-        check(lib.sc_hk_run(desc, self._state, self._hk, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
-                            ptr(self._nacq) if nac is not None else None, self._mc_norm(), dt, nt, ptr(partials), ptr(slots),
-                            ptr(self._elog), self._stream()))
+        for k0 in range(0, nt, chunk):
+            k = min(chunk, nt - k0)
+            check(lib.sc_hk_run(desc, self._state, self._hk, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
+                                ptr(self._nacq) if nac is not None else None, self._mc_norm(), dt, k, ptr(partials),
+                                slots.data_ptr() + 40 * k0, ptr(self._elog), self._stream()))
         self._run_scratch = partials          # alive until the stream has consumed it
         self._nsteps += nt
         for _ in range(nt):

@@ -598,6 +598,23 @@ def test_whole_loop_kernel_matches_stepwise_path_and_golden(name):
     assert abs(fused.autocorrelation(E0) - stepwise.autocorrelation(E0)) < 1e-13 * abs(stepwise.autocorrelation(E0))
 
 
+def test_whole_loop_kernel_long_run_goes_in_chunks():
+    """more steps than one launch takes (4096: the per-step partial sums of every wavefront are bounded): the launches of a
+    long run() continue each other on the device and fill consecutive slots; against the step-by-step path"""
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load("hk_1d")
+    nt, dt, E0 = 4096 + 37, float(g["dt"]) * 0.02, float(g["E0"])
+    fused, stepwise = engine_propagator(g), engine_propagator(g)
+    stepwise._whole_loop_ok = False
+    pot = engine_potential(g)
+    c1, k1 = fused.run(pot, dt, nt, E0)
+    c2, k2 = stepwise.run(pot, dt, nt, E0)
+    assert c1.shape == (nt,) and cases.rel_err(c1, c2) < 1e-12 and cases.rel_err(k1, k2) < 1e-12
+    assert torch.equal(fused._sgn, stepwise._sgn) and cases.rel_err(cnp(fused.y), cnp(stepwise.y)) < 1e-12
+    assert fused._nsteps == stepwise._nsteps == nt and abs(fused.t - stepwise.t) == 0.0
+    assert cases.rel_err(cnp(fused._elog), cnp(stepwise._elog)) < 1e-11
+
+
 def test_whole_loop_kernel_with_dense_blocks_and_ragged_batch():
     """random dense monodromy blocks (the fixed-order elimination meets weak pivots: in-kernel pivoted repeat), D = 12, and
     a batch that is not a multiple of 16"""
