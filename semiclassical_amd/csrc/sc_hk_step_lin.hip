@@ -521,6 +521,9 @@ int sc_launch_step_lin(const StepArgs &a, int grid, hipStream_t s) {
 #define SC_LIN_CASE(D_, DP_, DIAG_) if (D == D_ && dp == DP_ && diag == DIAG_) return launch<D_, DP_, DIAG_>(a, grid, s);
     SC_LIN_CASE(12, 6, false) SC_LIN_CASE(12, 12, true) SC_LIN_CASE(9, 3, false) SC_LIN_CASE(9, 9, true)
     SC_LIN_CASE(6, 6, true) SC_LIN_CASE(6, 6, false) SC_LIN_CASE(3, 3, true)
+    // further molecular shapes (D = 3 N Cartesian coordinates, d' = D - 6, or D - 5 for a linear molecule)
+    SC_LIN_CASE(6, 1, false) SC_LIN_CASE(9, 4, false) SC_LIN_CASE(12, 7, false) SC_LIN_CASE(15, 9, false)
+    SC_LIN_CASE(15, 15, true)
 #undef SC_LIN_CASE
     return 0;
 }

@@ -557,12 +557,13 @@ int launch(const WmArgs &a, int grid, hipStream_t s) {
 }  // namespace
 
 // instantiated shapes: full rank up to 8 modes, and the molecular cases of the reference's data (D = 3 N_atoms
-// Cartesian coordinates, d' = D - 6 vibrations): methylium (12, 6)
+// Cartesian coordinates, d' = D - 6 vibrations, D - 5 for linear molecules): methylium (12, 6)
 int sc_wm_launch_small(const WmArgs &a, int grid, hipStream_t s) {
     const int D = a.st.dim, dp = a.wc.dprime;
 #define SC_WM_CASE(D_, DP_) if (D == D_ && dp == DP_) return launch<D_, DP_>(a, grid, s);
     SC_WM_CASE(1, 1) SC_WM_CASE(2, 2) SC_WM_CASE(3, 3) SC_WM_CASE(4, 4) SC_WM_CASE(5, 5) SC_WM_CASE(6, 6)
     SC_WM_CASE(7, 7) SC_WM_CASE(8, 8) SC_WM_CASE(9, 3) SC_WM_CASE(12, 6)
+    SC_WM_CASE(6, 1) SC_WM_CASE(9, 4) SC_WM_CASE(12, 7)        // diatomic, linear triatomic, linear four-atom molecule (d' = D - 5)
 #undef SC_WM_CASE
     return 0;
 }

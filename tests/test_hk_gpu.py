@@ -368,7 +368,8 @@ def test_tiled_monodromy_layout_roundtrip_and_parity(D):
 
 
 @pytest.mark.parametrize("D,zero_modes,diag", [(12, 6, False), (12, 0, True), (9, 6, False), (9, 0, True),
-                                               (6, 0, True), (6, 0, False), (3, 0, True), (5, 0, True)])
+                                               (6, 0, True), (6, 0, False), (3, 0, True), (5, 0, True),
+                                               (6, 5, False), (9, 5, False), (12, 5, False), (15, 6, False), (15, 0, True)])
 def test_constant_hessian_register_kernel_vs_oracle(D, zero_modes, diag):
     """dense constant Hessian (MolecularHarmonicPotential) on random couplings: the shapes of the register kernel that
     multiplies with the RK4 step matrix (sc_hk_step_lin.hip), diagonal and projected prefactor, against the oracle's

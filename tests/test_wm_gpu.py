@@ -121,7 +121,7 @@ def _wm_vs_oracle(D, zero_modes, n, nt, seed, dense_gamma, alpha=60.0):
     return cases.rel_err(c, rc), cases.rel_err(k, rk), prop
 
 
-@pytest.mark.parametrize("D,zero_modes", [(2, 0), (3, 0), (4, 0), (6, 0), (7, 0), (8, 0), (9, 6), (12, 6)])
+@pytest.mark.parametrize("D,zero_modes", [(2, 0), (3, 0), (4, 0), (6, 0), (7, 0), (8, 0), (9, 6), (12, 6), (6, 5), (9, 5), (12, 5)])
 def test_wm_register_kernel_shapes(D, zero_modes):
     """every instantiated shape of the register-resident kernel (sc_wm_small.hip), dense width matrices, ragged n"""
     ec, ek, _ = _wm_vs_oracle(D, zero_modes, n=150, nt=10, seed=40 + D, dense_gamma=True)
