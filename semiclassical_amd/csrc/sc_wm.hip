@@ -118,7 +118,11 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     // constants: global pointers, or LDS copies when the host found room for them
     const double *cU = W.U, *cGt = W.Gt, *cG0 = W.G0, *ciGi0 = W.iGi0, *cS = W.S, *cCqq = W.Cqq;
     const double *cq0 = W.q0, *cp0 = W.p0, *cn1 = W.n1, *csn1 = W.s_n1, *cwn1 = W.w_n1;
-    if (A.stage_consts) {
+    // re-run of the trajectories the register kernel flagged (fixed pivot order too weak): nothing to do in the common case,
+    // not even the staging of the constants
+    const int32_t *only = A.only_flagged;
+    const bool idle = only && only[A.st.n] == 0;
+    if (A.stage_consts && !idle) {
         double *d = cst;
         auto stage = [&](const double *&ptr, int count) {
             if (ptr) { for (int i = tid; i < count; i += nth) d[i] = ptr[i]; ptr = d; }
@@ -133,9 +137,6 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     const double ihb = 1.0 / SC_HBAR;
     double acc[4] = {0, 0, 0, 0};
 
-    // re-run of the trajectories the register kernel flagged (fixed pivot order too weak): nothing to do in the common case
-    const int32_t *only = A.only_flagged;
-    const bool idle = only && only[A.st.n] == 0;
     for (int64_t tr = blockIdx.x; tr < A.st.n && !idle; tr += gridDim.x) {
         if (only && !only[tr]) continue;
         const double *qp = A.st.qp + tr * 2 * D, *zi = A.zi + tr * 2 * D;
