@@ -39,7 +39,7 @@ __device__ __forceinline__ int pair_index(int a, int b) {      // a != b; torch.
 }
 
 struct GdmlLds {
-    double *pos, *x, *gx, *fm, *em, *wm, *ea, *grad, *P, *Qn, *Z, *dg, *stage, *red;
+    double *pos, *x, *r, *gx, *fm, *em, *wm, *ea, *grad, *P, *Qn, *Z, *dg, *stage, *red;
     int XP;      // row stride of the MFMA operand arrays P = XJ, Qn = -e AJ, Z = w XJ - e AJ  ([GDML_CH][XP])
 };
 
@@ -82,6 +82,7 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int GDML_CH) {
     L.red = f;  f += 32;
     L.pos = f;  f += 3 * N;
     L.x = f;    f += Dd;
+    L.r = f;    f += Dd;           // distances 1 / x
     L.gx = f;   f += Dd;
     L.fm = f;   f += GDML_CH;
     L.em = f;   f += GDML_CH;
@@ -99,7 +100,7 @@ __device__ GdmlLds gdml_carve(double *base, int N, int Dd, int GDML_CH) {
 }
 
 size_t gdml_lds_doubles_ch(int N, int Dd, int GDML_CH, int nb) {
-    return 32 + 3 * N + 2 * (size_t)Dd + 4 * GDML_CH + 3 * N + (N & 1) + 9 * N + (N & 1) + 3 * (size_t)GDML_CH * gdml_xp(N) +
+    return 32 + 3 * N + 3 * (size_t)Dd + 4 * GDML_CH + 3 * N + (N & 1) + 9 * N + (N & 1) + 3 * (size_t)GDML_CH * gdml_xp(N) +
            (size_t)nb * 2 * (size_t)GDML_CH * Dd + 1;       // + 1: alignment pad of the stage
 }
 size_t gdml_lds_doubles(int N, int Dd) { const GdmlShape sh = gdml_shape(N); return gdml_lds_doubles_ch(N, Dd, sh.ch, sh.nb); }
@@ -153,7 +154,9 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         const int k = G.pair_k[d], l = G.pair_l[d];
         const double dx = L.pos[3 * k] - L.pos[3 * l], dy = L.pos[3 * k + 1] - L.pos[3 * l + 1],
                      dz = L.pos[3 * k + 2] - L.pos[3 * l + 2];
-        L.x[d] = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+        const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+        L.r[d] = dist;
+        L.x[d] = 1.0 / dist;
     }
     for (int e = tid; e < 3 * GDML_CH * L.XP; e += nth) L.P[e] = 0.0;       // P, Qn, Z are contiguous: padding columns stay 0
     __syncthreads();
@@ -386,31 +389,37 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     for (int j = 0; j < EPT; ++j)
         if (tid + nth * j < Dd) L.gx[tid + nth * j] = gacc[j] + gcomp[j];
     __syncthreads();
-    // ---- Cartesian gradient
-    for (int xi = tid; xi < X; xi += nth) {
-        const int a = xi / 3, u = xi - 3 * a;
-        double g = 0.0;
-        for (int b = 0; b < N; ++b) {
-            if (b == a) continue;
-            const int d = pair_index(a, b);
-            const double x = L.x[d];
-            g += jac(x * x * x, a, b, u) * L.gx[d];
+    // ---- Cartesian gradient grad = std J^T g_x and the diagonal atom blocks of the pair terms,
+    //      dg[a] = sum_c (-S jd jd^T + g d2x) = sum_c coef coef^T (3 g r - S) - 1 sum_c g x^3      (r = 1 / x, coef = -x^3 (r_a - r_c)),
+    // from the Jacobian coefficients the formation threads hold for their partners: gathers like J^T xs_m, by the first
+    // group of four threads per atom (each atom's 29 partners used to be walked by ONE thread per output element)
+    if (tid < PARTS * N) {
+        double g3[3] = {0.0, 0.0, 0.0}, h6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, tr3 = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < QN; ++cc) {
+            const int c = QN * fm_q + cc, d = pidx[cc];
+            const bool ok = c < N && c != fm_at;             // coef = 0 otherwise; the trace term needs the mask
+            const double x = L.x[d], g = ok ? L.gx[d] : 0.0, t = fma(3.0 * g, L.r[d], -S);
+            tr3 = fma(g, x * x * x, tr3);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) g3[u] = fma(coef[u][cc], g, g3[u]);
+            const double c0 = coef[0][cc] * t, c1 = coef[1][cc] * t, c2 = coef[2][cc] * t;
+            h6[0] = fma(c0, coef[0][cc], h6[0]); h6[1] = fma(c0, coef[1][cc], h6[1]); h6[2] = fma(c0, coef[2][cc], h6[2]);
+            h6[3] = fma(c1, coef[1][cc], h6[3]); h6[4] = fma(c1, coef[2][cc], h6[4]); h6[5] = fma(c2, coef[2][cc], h6[5]);
         }
-        L.grad[xi] = g * G.std;
-    }
-    // ---- Hessian.  Diagonal atom blocks of the pair terms: dg[a] = sum_c (-S jd jd^T + d2x) over the partners
-    for (int e = tid; e < 9 * N; e += nth) {
-        const int a = e / 9, u = (e - 9 * a) / 3, v = e - 9 * a - 3 * u;
-        double sum = 0.0;
-        for (int c = 0; c < N; ++c) {
-            if (c == a) continue;
-            const int d = pair_index(a, c);
-            // d2x / dr_u dr_v = 3 x^5 du dv - delta_uv x^3 with the displacement du = (r_a - r_c)[u] = jd[u] / (-x^3)
-            const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x;
-            const double du = L.pos[3 * a + u] - L.pos[3 * c + u], dv = L.pos[3 * a + v] - L.pos[3 * c + v];
-            sum += -S * (x3 * du) * (x3 * dv) + 3.0 * g * x5 * du * dv - (u == v ? g * x3 : 0.0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) g3[u] = parts_sum(g3[u]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h6[i] = parts_sum(h6[i]);
+        tr3 = parts_sum(tr3);
+        if (fm_q == 0) {
+            double *dg = L.dg + 9 * fm_at;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) L.grad[3 * fm_at + u] = g3[u] * G.std;
+            dg[0] = h6[0] - tr3; dg[1] = h6[1]; dg[2] = h6[2];
+            dg[3] = h6[1]; dg[4] = h6[3] - tr3; dg[5] = h6[4];
+            dg[6] = h6[2]; dg[7] = h6[4]; dg[8] = h6[5] - tr3;
         }
-        L.dg[e] = sum;
     }
     __syncthreads();
     // atom-pair terms element by element, scale, write both triangles
