@@ -38,8 +38,11 @@ struct RunArgs {
 // value of `v` in lane 0 of each 16-lane row, summed over the four rows of the wavefront (result in every lane)
 __device__ __forceinline__ double sum_row_heads(double v, bool head) { return wave_sum(head ? v : 0.0); }
 
+#ifndef SC_RUN_OCC
+#define SC_RUN_OCC 2
+#endif
 template <int DP, int KIND>
-__global__ __launch_bounds__(256, 2) void hk_run_sep16_kernel(RunArgs R) {
+__global__ __launch_bounds__(256, SC_RUN_OCC) void hk_run_sep16_kernel(RunArgs R) {
     const StepArgs &A = R.step;
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x, lane = tid & 63, r = tid & 15, grp = tid >> 4, wave = tid >> 6;
     const int rowbase = tid & 48;
