@@ -188,3 +188,24 @@ def test_dpp_hazards():
     bad, n_dpp = chk.scan(chk.disassemble(build.LIB))[:2]
     assert n_dpp > 1000, "the disassembly did not reach the device code"
     assert not bad, bad[:5]
+
+
+def test_cursor_handover_is_fenced_in_the_source():
+    """hk_step_sd_kernel hands the next trajectory index from thread 0 to the other wavefronts through LDS; the round-2 GPU
+    memory fault was a variant in which no barrier lay between the write and the reads.  The barrier
+    must be unconditional (not inside a variant macro or a template branch) and sit between the two in the source."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "semiclassical_amd", "csrc", "sc_hk_step_sd.hip")).read()
+    src = "\n".join(line.split("//")[0] for line in src.splitlines())            # comments stripped
+    write = src.index("nextbuf[par] = drawn;")
+    reads = [m.start() for m in re.finditer(r"readfirstlane\(nextbuf\[par\]\)", src)]
+    assert reads and all(r > write for r in reads)
+    code = src[write:min(reads)]
+    assert "__syncthreads();" in code
+    barrier_line = [l for l in code.splitlines() if "__syncthreads();" in l][0]
+    assert barrier_line.strip() == "__syncthreads();", "the reset barrier must not be conditional"
+    assert "#if" not in code[:code.index("__syncthreads();")] and "#endif" not in code[:code.index("__syncthreads();")]
+    # the two LDS words are defined before the first trajectory
+    assert re.search(r"nextbuf\[tid\] = 0; weakbuf\[tid\] = 0;", src)
