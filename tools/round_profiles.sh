@@ -16,5 +16,12 @@ python tools/kernel_stats.py $out/bench $dst/${tag}_bench_kernel_stats.csv \
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmc_write.log 2>&1
 python tools/hbm_traffic.py $out/pmc_fetch $out/pmc_write $dst/${tag}_hbm_traffic.json > /dev/null
+# SQ counters of the headline kernels (two passes, as for the other configurations)
+A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU"
+B="SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+rocprofv3 --kernel-trace --pmc $A -d $out/pmcA_bench -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmcA_bench.log 2>&1
+rocprofv3 --kernel-trace --pmc $B -d $out/pmcB_bench -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmcB_bench.log 2>&1
+python tools/pmc_summary.py $dst/${tag}_bench_pmc.json "headline configuration (60-mode AS, n = 1e5, HK): SQ counters of the step, modes and correlation kernels, two rocprofv3 --pmc passes" \
+    hk_step_sd_kernel,hk_modes_kernel,hk_correlate_kernel $out/pmcA_bench $out/pmcB_bench > /dev/null
 echo "headline done"
 tools/profile_configs.sh $tag
