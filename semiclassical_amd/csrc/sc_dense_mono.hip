@@ -453,16 +453,33 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)src + (unsigned)soff[j]),
                                              (__attribute__((address_space(3))) void *)(Hs0 + (size_t)buf * D * HSB + 2 * u0), 16, 0, 0);
     };
-    const int64_t items = A.st.n * NSLAB;
-    if ((int64_t)blockIdx.x < items) {
-        const double *H0 = A.hess + ((int64_t)blockIdx.x / NSLAB) * A.hess_stride;
+    // Work items = (trajectory, slab).  The NSLAB slabs of a trajectory read the SAME four Hessian images (NSLAB x 4 x 8 D^2
+    // bytes of the launch's traffic): workgroup b lands on XCD b % 8 (round-robin dispatch), so the slabs of a trajectory are
+    // dealt to workgroups of ONE XCD -- b = 8 q + xcd takes trajectory 8 (q / NSLAB) + xcd, slab q % NSLAB -- and meet in its L2
+    // instead of fetching the images NSLAB times over the fabric (FETCH_SIZE 11.4 GB per launch at D = 90, n = 1e4, against
+    // 5.2 GB algorithmic).  Needs a grid that is a multiple of 8; the virtual item range is rounded up, items beyond n skipped.
+    const bool by_xcd = (gridDim.x & 7) == 0;
+    const int64_t n_round = by_xcd ? (A.st.n + 7) / 8 * 8 : A.st.n, items = n_round * NSLAB;
+    auto trajectory_of = [&](int64_t item, int &slab) -> int64_t {
+        if (!by_xcd) { slab = (int)(item % NSLAB); return item / NSLAB; }
+        const int64_t q = item >> 3;
+        slab = (int)(q % NSLAB);
+        return (q / NSLAB) * 8 + (item & 7);
+    };
+    // first item of this workgroup with a trajectory (the virtual range has holes beyond n)
+    int64_t first = blockIdx.x;
+    { int sl; while (first < items && trajectory_of(first, sl) >= A.st.n) first += gridDim.x; }
+    if (first < items) {
+        int sl;
+        const double *H0 = A.hess + trajectory_of(first, sl) * A.hess_stride;
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) request(H0, 0, j);                   // stage 0 of the first slab (the only unhidden image)
     }
     int g = 0;                                                               // stages this workgroup has started: image g & 1
-    for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const int64_t tr = item / NSLAB;
-        const int ct = 4 * (int)(item - tr * NSLAB) + wave;                  // column tile of [X | X'] this wavefront owns
+    for (int64_t item = first; item < items; ) {
+        int slab;
+        const int64_t tr = trajectory_of(item, slab);
+        const int ct = 4 * slab + wave;                                      // column tile of [X | X'] this wavefront owns
         const bool active = ct < 2 * NT;
         const int pair = active ? ct / NT : 0, jt = active ? ct % NT : 0;    // pair 0: (Mqq, Mpq), pair 1: (Mqp, Mpp)
         const int col = 16 * jt + (lane & 15);
@@ -470,8 +487,10 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
         const unsigned toff = (unsigned)(rg * D + col);
         double *Mx = A.st.mono + tr * 4 * (int64_t)DD + (int64_t)pair * DD, *My = Mx + 2 * (int64_t)DD;
         const double *Hg = A.hess + tr * A.hess_stride;
-        const int64_t nitem = item + gridDim.x;
-        const double *Hnext_item = nitem < items ? A.hess + (nitem / NSLAB) * A.hess_stride : nullptr;
+        int64_t nitem = item + gridDim.x;
+        int nslab;
+        while (nitem < items && trajectory_of(nitem, nslab) >= A.st.n) nitem += gridDim.x;
+        const double *Hnext_item = nitem < items ? A.hess + trajectory_of(nitem, nslab) * A.hess_stride : nullptr;
         double SX[NT][4], SY[NT][4], Xs[NT][4], Ys[NT][4], X0[NT][4], Y0[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -540,6 +559,7 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
                     (My + (16 * t + 4 * r) * D)[toff] = fma(h6, SY[t][r], Y0[t][r]);
                 }
             }
+        item = nitem;
     }
 }
 
