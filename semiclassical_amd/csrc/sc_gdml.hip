@@ -440,8 +440,10 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                 fin = S * (x3 * du) * (x3 * dv) - (3.0 * g * x5 * du * dv - (u == v ? g * x3 : 0.0));
             }
             const double val = (acc[sl][qq] + fin) * G.std;
-            hess[(size_t)xr * X + y] = val;
-            hess[(size_t)y * X + xr] = val;
+            // written once, read by the monodromy kernel after the stage: non-temporal, so that the 65 KB per geometry do not
+            // push the training set (read by every workgroup) out of the XCD's L2
+            __builtin_nontemporal_store(val, &hess[(size_t)xr * X + y]);
+            __builtin_nontemporal_store(val, &hess[(size_t)y * X + xr]);
         }
     }
     __syncthreads();
