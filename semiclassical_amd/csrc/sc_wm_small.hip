@@ -150,7 +150,13 @@ __global__ __launch_bounds__(256, SC_WM_SMALL_OCC) void wm_small_kernel(WmArgs A
 
     double *xr = xall + grp * L::xbuf;          // transposition buffer of this trajectory
     const int64_t n = A.st.n, stride = (int64_t)gridDim.x * 16;
-    for (int64_t t0 = (int64_t)blockIdx.x * 16; t0 < n; t0 += stride) {
+    // The passes run from the LAST trajectories to the first: the step kernel in front of this launch wrote the monodromy
+    // blocks in ascending order, so the highest ones are what the memory-side cache (256 MB of a 460 MB state at n = 1e5)
+    // still holds; and the next step kernel, ascending again, starts on what this launch read last.
+    const int64_t first_t0 = (int64_t)blockIdx.x * 16;
+    const int64_t npass = first_t0 < n ? (n - first_t0 + stride - 1) / stride : 0;
+    for (int64_t pass = npass - 1; pass >= 0; --pass) {
+        const int64_t t0 = first_t0 + pass * stride;
         const bool active = t0 + grp < n;
         const int64_t tr = active ? t0 + grp : n - 1;      // idle rows redo the last trajectory and discard it
         const double *qp = A.st.qp + tr * 2 * D, *zi = A.zi + tr * 2 * D;
