@@ -34,14 +34,20 @@ __global__ __launch_bounds__(256) void mfma_chain(double *out, unsigned long lon
     const double *row = lds + wave * 16 * 64 + lane;     // one double per lane and row: conflict-free
     const unsigned long long t0 = clock64(), r0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
+        double fa[NACC], fb[NACC];
+        if (FEED == 1) {                                           // all operand reads of the iteration first, then the products
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) {
+                const double *p = row + ((it + j) & 7) * 128;      // the address changes with the iteration: no hoisting
+                fa[j] = p[0];
+                fb[j] = p[64];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NACC; ++j) {
-            if (FEED == 1) {
-                const double *p = row + ((it + j) & 7) * 128;      // the address changes with the iteration: no hoisting
-                a = p[0];
-                b = p[64];
-            }
-            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            // inline assembly: with the builtin hipcc copies every accumulator VGPR <-> AGPR once per iteration
+            if (FEED == 1) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(fa[j]), "v"(fb[j]));
+            else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
             if (FEED == 2) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(v[j]) : "v"(a), "v"(b));
         }
     }
@@ -50,7 +56,11 @@ __global__ __launch_bounds__(256) void mfma_chain(double *out, unsigned long lon
 #pragma unroll
     for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3] + v[j];
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+    if (threadIdx.x == 0) {          // per workgroup: shader cycles of the loop, its begin and end on the 100 MHz clock
+        clk[3 * blockIdx.x] = t1 - t0;
+        clk[3 * blockIdx.x + 1] = r0;
+        clk[3 * blockIdx.x + 2] = r1;
+    }
 }
 
 template <int NACC, int FEED>
@@ -68,21 +78,31 @@ static void run(int waves_per_simd, double *out, unsigned long long *clk, const 
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
     }
-    unsigned long long h[2];
-    CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+    static unsigned long long h[3 * 1024];
+    CHECK(hipMemcpy(h, clk, sizeof(unsigned long long) * 3 * grid, hipMemcpyDeviceToHost));
     const double instr_per_wave = (double)iters * NACC;
     const double flops = 2048.0 * instr_per_wave * grid * 4;
-    const double mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;          // s_memrealtime ticks at 100 MHz
-    const double cyc = (double)h[0] / (instr_per_wave * waves_per_simd);           // shader cycles per MFMA per SIMD
-    printf("%-28s acc tiles %d  waves/SIMD %d : %8.3f ms  %6.1f TFLOP/s  %6.1f shader cycles per MFMA per SIMD  clock %5.0f MHz\n",
-           feed, NACC, waves_per_simd, best, flops / (best * 1e-3) / 1e12, cyc, mhz);
+    // how many workgroups were resident at a time: sum of the workgroups' loop durations over the span of the launch
+    unsigned long long first = ~0ull, last = 0;
+    double busy = 0.0, cycles = 0.0;
+    for (int g = 0; g < grid; ++g) {
+        if (h[3 * g + 1] < first) first = h[3 * g + 1];
+        if (h[3 * g + 2] > last) last = h[3 * g + 2];
+        busy += (double)(h[3 * g + 2] - h[3 * g + 1]);
+        cycles += (double)h[3 * g];
+    }
+    const double resident = busy / (double)(last - first) / 256.0;                 // workgroups (= waves per SIMD) resident per CU
+    const double mhz = 100.0 * cycles / busy;                                      // s_memrealtime ticks at 100 MHz
+    const double cyc = cycles / grid / (instr_per_wave * resident);                // shader cycles per MFMA per SIMD
+    printf("%-28s acc tiles %d  waves/SIMD %d (resident %.2f): %8.3f ms  %6.1f TFLOP/s  %6.1f shader cycles per MFMA per SIMD  clock %5.0f MHz\n",
+           feed, NACC, waves_per_simd, resident, best, flops / (best * 1e-3) / 1e12, cyc, mhz);
 }
 
 int main() {
     double *out;
     unsigned long long *clk;
     CHECK(hipMalloc(&out, sizeof(double) * 256 * 4 * 256));
-    CHECK(hipMalloc(&clk, 2 * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&clk, 3 * 1024 * sizeof(unsigned long long)));
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     printf("# %s, %d CUs, clockRate %d kHz; v_mfma_f64_16x16x4_f64 = 2048 flop per wave instruction\n", prop.name,
