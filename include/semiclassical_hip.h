@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        13
+#define SC_ABI_VERSION        14
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -372,6 +372,32 @@ int sc_wm_pair_sum(const double *qp, const double *coef, const double *cqq, cons
  * The mean of this step is formed from energy_partials; the host raises the reference's RuntimeError when
  * elog[2] > 1e-2 Hartree the next time it synchronises. */
 int sc_energy_guard(const double *energy_partials, int32_t n_blocks, double n_traj, double *elog, void *stream);
+
+/* ---- multi-GPU flush -------------------------------------------------------------------------
+ * Trajectories shard over the GPUs of a node, one process per GPU; every term of C_auto / k_ic already carries the weight
+ * 1/(N_total P(q_i, p_i)) (propagators.py:837, 909), so the functions of the whole ensemble are the plain SUM of the
+ * per-rank slot buffers -- the running mean of cli.py:453-458 over one repetition, taken across ranks.
+ * sc_flush_allreduce is that sum: ONE ncclAllReduce(ncclDouble, ncclSum), in place, on `stream` (RCCL over xGMI), of
+ * `count` doubles -- the caller passes the packed 4 nt sums, or the whole [nt][5] slot buffer of sc_reduce_slot_at /
+ * sc_hk_run (column 4, the per-rank mean <T+V>, then holds the sum of the ranks' means).  Nothing else on the hot path
+ * is a collective.
+ *
+ * librccl is loaded at the first sc_comm_* call (dlopen of librccl.so.1 from the loader's search path): no link-time
+ * dependency, single-GPU users never load it.
+ *   sc_comm_available   RCCL's version code (ncclGetVersion) if the library can be loaded, 0 otherwise
+ *   sc_comm_unique_id   ncclGetUniqueId -> id_out[SC_COMM_ID_BYTES]; ONE rank calls it and hands the bytes to the others by
+ *                       whatever host channel the application has (file, socket, MPI, torch's TCPStore)
+ *   sc_comm_init        ncclCommInitRank on the CURRENT HIP device; collective over the nranks processes
+ *   sc_comm_rank_count  rank and size of a communicator (either output may be NULL)
+ *   sc_comm_destroy     ncclCommDestroy (NULL is accepted)
+ * Returns SC_ERR_UNSUPPORTED when librccl cannot be loaded, SC_ERR_LAUNCH with RCCL's message on an RCCL error. */
+#define SC_COMM_ID_BYTES 128
+int sc_comm_available(void);
+int sc_comm_unique_id(void *id_out);
+int sc_comm_init(const void *id, int32_t nranks, int32_t rank, void **comm_out);
+int sc_comm_rank_count(void *comm, int32_t *rank_out, int32_t *nranks_out);
+int sc_comm_destroy(void *comm);
+int sc_flush_allreduce(double *sums, int64_t count, void *comm, void *stream);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 13              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 14              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch)
 
@@ -139,6 +139,12 @@ SIGNATURES = {
     "sc_reduce_slot_at": (C.c_int, [c_double_p, C.c_int32, c_double_p, C.c_void_p, C.c_void_p]),
     "sc_reduce_slot": (C.c_int, [c_double_p, C.c_int32, c_double_p, C.c_int32, C.c_double, c_double_p,
                                  C.c_void_p]),
+    "sc_comm_available": (C.c_int, []),
+    "sc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "sc_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, P(C.c_void_p)]),
+    "sc_comm_rank_count": (C.c_int, [C.c_void_p, P(C.c_int32), P(C.c_int32)]),
+    "sc_comm_destroy": (C.c_int, [C.c_void_p]),
+    "sc_flush_allreduce": (C.c_int, [c_double_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }
 
 

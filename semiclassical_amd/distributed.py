@@ -10,7 +10,14 @@ collective exists on the path.
 
 Process model: one process per GPU.  ``launch_local_ranks`` starts the rank processes of one node from a
 parent that never touches the GPU (it only counts to N and waits); ``init_from_env`` is what every rank
-calls first.  This module does not import the HIP engine.
+calls first.  This module does not import the HIP engine at import time (``RcclCommunicator`` binds it when
+it is constructed, inside a rank process).
+
+Two transports for the flush:
+  * a ``torch.distributed`` process group (``nccl`` = RCCL on ROCm, or ``gloo``): ``flush_correlations(slots)``;
+  * the C-ABI's own binding of librccl, ``sc_flush_allreduce`` (include/semiclassical_hip.h), for consumers
+    without torch.distributed: ``flush_correlations(slots, comm=RcclCommunicator(...))`` -- the only thing
+    that crosses processes on the host side is RCCL's 128-byte unique id.
 """
 import os
 import socket
@@ -50,7 +57,10 @@ def rank_environment(rank, world, port, base=None):
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    # dmabuf IPC: the build image's environment notes say this host driver supports only dmabuf IPC and that RCCL /
+    # device-memory sharing across processes fails with "hipIpcGetMemHandle: invalid argument" without it (the image exports
+    # it already; kept for ranks started from a scrubbed environment).  Not verified here: the boxes have one GPU.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env
 
 
@@ -109,13 +119,77 @@ def shard_slice(n_total, rank, world):
     return slice(lo, lo + shard_count(n_total, rank, world))
 
 
-def flush_correlations(slots, group=None):
+class RcclCommunicator(object):
+    """An RCCL communicator owned through the C-ABI (``sc_comm_init`` / ``sc_flush_allreduce``): the flush without
+    torch.distributed.  Collective constructor -- every rank of the job builds one on ITS device.
+
+    The unique id travels over a host channel: ``store`` is anything with ``set(key, bytes)`` / ``get(key) -> bytes``
+    (a ``torch.distributed.TCPStore``, which needs no process group); without one, an initialised process group
+    broadcasts it, or a TCPStore is opened on MASTER_ADDR : MASTER_PORT + 1.
+    """
+
+    def __init__(self, rank, world, device, store=None, key="sc_rccl_unique_id"):
+        import ctypes
+        from ._lib import lib, check
+        self._lib, self._check = lib, check
+        self.rank, self.world, self.device = int(rank), int(world), torch.device(device)
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib.sc_comm_unique_id(uid))
+        if self.world > 1:
+            uid = ctypes.create_string_buffer(self._exchange(bytes(uid.raw), store, key), 128)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.sc_comm_init(uid, self.world, self.rank, ctypes.byref(handle)))
+        self.handle = handle
+
+    def _exchange(self, mine, store, key):
+        if store is None and dist.is_available() and dist.is_initialized():
+            box = [mine if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        if store is None:
+            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29511")) + 1,
+                                  self.world, is_master=(self.rank == 0))
+            self._store = store                                     # the server side has to outlive the clients' get()
+        if self.rank == 0:
+            store.set(key, mine)
+            return mine
+        return bytes(store.get(key))
+
+    def all_reduce_sum(self, t):
+        """sum of the contiguous float64 device tensor ``t`` over the ranks, in place, on torch's current stream"""
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        import ctypes
+        self._check(self._lib.sc_flush_allreduce(ctypes.c_void_p(t.data_ptr()), t.numel(), self.handle, stream))
+        return t
+
+    def rank_count(self):
+        import ctypes
+        r, n = ctypes.c_int32(), ctypes.c_int32()
+        self._check(self._lib.sc_comm_rank_count(self.handle, ctypes.byref(r), ctypes.byref(n)))
+        return r.value, n.value
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self._check(self._lib.sc_comm_destroy(self.handle))
+            self.handle = None
+
+
+def flush_correlations(slots, group=None, comm=None):
     """sum the raw per-step correlation sums over all ranks, in place (columns 0..3 of ``slots``).
 
     Column 4 (reserved) is left rank-local.  A single collective per call.  With the ``gloo`` backend a
     device tensor is staged through the host (gloo reduces host memory); with ``nccl`` (RCCL) the
-    reduction runs on the device buffers directly.
+    reduction runs on the device buffers directly.  ``comm``: an ``RcclCommunicator`` -- the same single
+    all-reduce through the C-ABI's ``sc_flush_allreduce`` instead of torch.distributed.
     """
+    if comm is not None:
+        buf = slots[:, :4].contiguous()
+        comm.all_reduce_sum(buf)
+        slots[:, :4] = buf
+        return slots
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return slots
     buf = slots[:, :4].contiguous()
@@ -129,8 +203,38 @@ def flush_correlations(slots, group=None):
     return slots
 
 
+class _Local(object):
+    """sentinel group: "this rank only" (the default of the O(n^2) diagnostics, which must not turn into collectives
+    just because a process group exists)"""
+
+    def __repr__(self):
+        return "LOCAL"
+
+
+LOCAL = _Local()
+
+
 def _active(group=None):
+    if group is LOCAL:
+        return False
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if _active(group) else 1
+
+
+def get_rank(group=None):
+    return dist.get_rank(group) if _active(group) else 0
+
+
+def broadcast_object(obj, src=0, group=None):
+    """``obj`` of rank ``src`` on every rank (host objects: seeds, small configuration)"""
+    if not _active(group):
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
 
 
 def all_gather_rows(t, group=None):

@@ -158,21 +158,44 @@ def make_propagator(task, Gamma_0, device):
     return propagators.HermanKlukPropagator(Gamma_0, Gamma_0, device=device)
 
 
-def propagate_batch(propagator, setup, dt, nt, times, norm_every=0):
-    """C_auto(t), k_ic(t) of one batch of trajectories.  ``norm_every`` > 0 logs the wavefunction norm (the O(n^2)
-    convergence diagnostic of cli.py:424-429) at every norm_every-th step by cutting the device loop there."""
-    if norm_every <= 0:
-        return propagator.run(setup.potential, dt, nt, energy0_es=setup.zero_point_energy)
+def propagate_batch(propagator, setup, dt, nt, times, norm_every=0, flush=None, across_ranks=False, log=True):
+    """C_auto(t), k_ic(t) of one batch of trajectories: the device loop leaves the raw per-step sums in a device buffer,
+    ``flush`` (None on a single rank) adds the buffers of all ranks -- ONE all-reduce per batch, SURVEY 8e -- and the host
+    applies the dynamical phase.  ``norm_every`` > 0 logs the wavefunction norm (the O(n^2) convergence diagnostic of
+    cli.py:424-429) at every norm_every-th step by cutting the device loop there; with ``across_ranks`` it is the norm of
+    the whole sharded batch (a collective: every rank calls it, ``log`` says who prints)."""
+    slots = torch.zeros((nt, 5), dtype=torch.float64, device=propagator.device)
+    length = norm_every if norm_every > 0 else nt
     pieces = []
-    for first in range(0, nt, norm_every):
-        logger.info(f" time/fs= {times[first] * units.autime_to_fs}  norm= {propagator.norm():9.6f}")
-        pieces.append(propagator.run(setup.potential, dt, min(norm_every, nt - first),
-                                     energy0_es=setup.zero_point_energy))
-    return tuple(np.concatenate(part) for part in zip(*pieces))
+    for first in range(0, nt, length):
+        if norm_every > 0:
+            norm = propagator.norm(across_ranks=across_ranks)
+            if log:
+                logger.info(f" time/fs= {times[first] * units.autime_to_fs}  norm= {norm:9.6f}")
+        count = min(length, nt - first)
+        pieces.append((first, count, propagator.t))
+        propagator.run(setup.potential, dt, count, slots=slots[first:first + count])
+    if flush is not None:
+        flush(slots)
+    propagator.synchronize()                      # raises the energy-conservation error of this rank's trajectories
+    parts = [propagator.finalize_slots(slots[first:first + count], t0, dt, setup.zero_point_energy)
+             for first, count, t0 in pieces]
+    return tuple(np.concatenate(part) for part in zip(*parts))
 
 
-def run_semiclassical_dynamics(task, device='cuda'):
+def run_semiclassical_dynamics(task, device='cuda', comm=None):
+    """One 'dynamics' task.  Under ``torch.distributed`` with more than one rank (``python -m semiclassical_amd.driver
+    dynamics input.json --gpus N`` or torchrun; north_star: "trajectory batches shard embarrassingly across the 8 GPUs of
+    one node with a single RCCL all-reduce ... per flush") every rank integrates ITS share of each batch of the
+    reference's repetition loop (cli.py:321-324, 374-476) on its own GPU with the batch size as Monte-Carlo weight, one
+    all-reduce per batch adds the raw sums, and rank 0 keeps the result file.  ``comm``: an
+    ``distributed.RcclCommunicator`` to flush through the C-ABI's sc_flush_allreduce instead of the process group."""
+    from . import distributed as Dm
     torch.set_default_dtype(torch.float64)
+    rank, world = Dm.get_rank(), Dm.world_size()
+    if comm is not None:
+        rank, world = comm.rank, comm.world
+    writer = rank == 0
     setup = build_problem(task)
 
     dt = task['time_step_fs'] / units.autime_to_fs
@@ -184,35 +207,59 @@ def run_semiclassical_dynamics(task, device='cuda'):
     num_trajectories = task.get('num_trajectories', 50000)
     repetitions = max(num_trajectories // batch_size, 1)
     per_batch = min(batch_size, num_trajectories)
+    mine = Dm.shard_slice(per_batch, rank, world)            # this rank's trajectories of every batch
+    if mine.stop == mine.start:
+        raise ConfigurationError(f"batches of {per_batch} trajectories cannot be shared by {world} ranks")
 
     store = CorrelationStore(task['results'].get('correlations', 'correlations.npz'))
-    store.start(task, task.get('propagator', 'HK'), times, setup)
+    if writer:
+        store.start(task, task.get('propagator', 'HK'), times, setup)
 
     seed = task.get('manual_seed', None)
     if seed is not None:
         logger.warning("The random number generator should not be seeded manually unless for debugging!")
-        torch.manual_seed(seed)
     # Where the phase-space points are drawn (a key the reference does not have; it samples on its compute device,
     # cli.py:392 -> propagators.py:537-539): "device" = sc_sample_initial (counter-based Philox keyed by the seed, one
-    # subsequence per repetition, nothing crosses PCIe), "host" = torch's CPU generator as in the reference's CPU runs.
+    # subsequence per repetition, nothing crosses PCIe; a rank draws ITS slice of the batch), "host" = torch's CPU
+    # generator as in the reference's CPU runs (ranks sharing a batch all draw the whole batch from the same seed).
     sampling = task.get('sampling', 'device')
     if sampling not in ('device', 'host'):
         raise ValueError("'sampling' should be one of 'device' or 'host'")
-    device_seed = int(seed) if seed is not None else int.from_bytes(os.urandom(8), 'little')
+    if seed is None and world > 1:
+        seed_all = Dm.broadcast_object(int.from_bytes(os.urandom(7), 'little'))     # fresh entropy, the same on every rank
+    else:
+        seed_all = seed
+    if seed_all is not None and (seed is not None or sampling == 'host'):
+        torch.manual_seed(seed_all)
+    device_seed = int(seed_all) if seed_all is not None else int.from_bytes(os.urandom(8), 'little')
+
+    if comm is not None:
+        flush = lambda slots: Dm.flush_correlations(slots, comm=comm)
+    elif world > 1:
+        flush = Dm.flush_correlations
+    else:
+        flush = None
 
     for repetition in range(repetitions):
         logger.info(f"*** Repetition {repetition + 1} ***")
         propagator = make_propagator(task, setup.Gamma_0, device)
+        count = mine.stop - mine.start
         if sampling == 'device':
-            propagator.initial_conditions(setup.q0, setup.p0, setup.Gamma_0, ntraj=per_batch, seed=device_seed,
-                                          subsequence=repetition)
-        else:
+            propagator.initial_conditions(setup.q0, setup.p0, setup.Gamma_0, ntraj=count, ntraj_total=per_batch,
+                                          seed=device_seed, subsequence=repetition, first_index=mine.start)
+        elif world == 1:
             propagator.initial_conditions(setup.q0, setup.p0, setup.Gamma_0, ntraj=per_batch)
+        else:
+            zi, probi = propagator.draw_initial_conditions(setup.q0, setup.p0, setup.Gamma_0, per_batch)
+            propagator.set_initial_conditions(setup.q0, setup.p0, setup.Gamma_0, zi[:, mine], probi[mine],
+                                              ntraj_total=per_batch)
         autocorrelation, ic_correlation = propagate_batch(propagator, setup, dt, nt, times,
-                                                          norm_every=task.get('calc_norm_every', 0))
+                                                          norm_every=task.get('calc_norm_every', 0), flush=flush,
+                                                          across_ranks=world > 1 and comm is None, log=writer)
         assert not np.isnan(autocorrelation).any(), f"encountered NaN's in autocorrelation : {autocorrelation}"
         assert not np.isnan(ic_correlation).any(), f"encountered NaN's in IC correlation : {ic_correlation}"
-        store.add_batch(autocorrelation, ic_correlation, per_batch)
+        if writer:
+            store.add_batch(autocorrelation, ic_correlation, per_batch)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -251,17 +298,38 @@ def main(argv=None):
     sub = parser.add_subparsers(dest='command')
     dyn = sub.add_parser('dynamics', help="run semiclassical dynamics")
     dyn.add_argument('json_input', type=str, metavar='input.json')
-    dyn.add_argument('--cuda', type=int, default=0, metavar='id')
+    dyn.add_argument('--cuda', type=int, default=None, metavar='id',
+                     help="GPU of this process (default: 0, or LOCAL_RANK in a multi-rank job)")
+    dyn.add_argument('--gpus', type=int, default=1, metavar='N',
+                     help="share every batch of trajectories among N GPUs of this node: starts N rank processes (one per "
+                          "GPU, RCCL process group) unless a launcher (torchrun) has already done so")
     rat = sub.add_parser('rates', help="Fourier transform correlation functions into rates")
     rat.add_argument('json_input', type=str, metavar='input.json')
     args = parser.parse_args(argv)
+    if args.command == 'dynamics' and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: this parent never touches the GPU, it starts one rank process per GPU and waits for them
+        import sys
+        from . import distributed as Dm
+        forwarded = list(sys.argv[1:] if argv is None else argv)
+        raise SystemExit(Dm.launch_local_ranks(["-m", "semiclassical_amd.driver"] + forwarded, args.gpus))
     with open(args.json_input) as f:
         config = json.load(f)
-    handlers = {'dynamics': lambda task: run_semiclassical_dynamics(task, device=f"cuda:{args.cuda}"),
-                'rates': calculate_rates}
+    if args.command == 'dynamics':
+        from . import distributed as Dm
+        rank, world, local = Dm.init_from_env()
+        cuda = args.cuda if args.cuda is not None else (local if world > 1 else 0)
+        if world > 1 and rank != 0:
+            logging.getLogger().setLevel(logging.WARNING)          # one voice per job
+        handler = lambda task: run_semiclassical_dynamics(task, device=f"cuda:{cuda}")
+    else:
+        world, handler = 1, calculate_rates
     for task in config['semi']:
         if task['task'] == args.command:
-            handlers[args.command](task)
+            handler(task)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -123,6 +123,11 @@ class HermanKlukPropagator(object):
             self.zi = self._zi_t.t()                   # the reference's (2D, n) attribute, as a view
             self._finish_state((ilz_d, z0_d))
             return
+        zi, probi = self._draw_on_host(z0, iLz, prob0, dprime, ntraj, generator)
+        self.set_initial_conditions(q0, p0, Gamma_0, zi, probi, ntraj_total=ntraj_total)
+
+    @staticmethod
+    def _draw_on_host(z0, iLz, prob0, dprime, ntraj, generator=None):
         if generator is None:
             xi = torch.distributions.Normal(torch.zeros(2 * dprime, dtype=F64),
                                             torch.ones(2 * dprime, dtype=F64)).sample((ntraj,)).T
@@ -130,7 +135,16 @@ class HermanKlukPropagator(object):
             xi = torch.randn((ntraj, 2 * dprime), dtype=F64, generator=generator).T
         zi = z0.unsqueeze(1) + torch.einsum('ji,jn->in', iLz, xi)
         probi = prob0 * torch.exp(-0.5 * torch.einsum('in,in->n', xi, xi))
-        self.set_initial_conditions(q0, p0, Gamma_0, zi, probi, ntraj_total=ntraj_total)
+        return zi, probi
+
+    def draw_initial_conditions(self, q0, p0, Gamma_0, ntraj, generator=None):
+        """The host draw of ``initial_conditions`` without touching the state: ``(zi (2D, ntraj), probi (ntraj,))`` from
+        torch's CPU generator with the call the reference makes (propagators.py:537-566).  Ranks that share one batch
+        all draw the whole batch from the same seed and hand their slice to ``set_initial_conditions``."""
+        q0, p0, Gamma_0 = hostmath.as_f64(q0), hostmath.as_f64(p0), hostmath.as_f64(Gamma_0)
+        _, _, iLz, detLz, dprime = hostmath.sampling_matrices(self._Gi, Gamma_0)
+        prob0 = detLz / (2 * np.pi) ** q0.size()[0]
+        return self._draw_on_host(torch.cat((q0, p0)), iLz, prob0, dprime, int(ntraj), generator)
 
     def set_initial_conditions(self, q0, p0, Gamma_0, zi, probi, ntraj_total=None):
         """Start from given phase-space points ``zi`` (2D, n) with sampling densities ``probi`` (n,)."""
@@ -654,17 +668,36 @@ class HermanKlukPropagator(object):
         v = self.semiclassical_prefactor() * torch.exp(1j / hbar * self._act) * self._vi
         return v / (self._mc_norm() * self.probi)
 
-    def norm(self, group=None):
+    def _norm_group(self, across_ranks, group):
+        """process group of a cross-rank norm(), or the LOCAL sentinel.  Cross-rank is OPT-IN: a process group that merely
+        exists (ranks propagating independent ensembles, rank-0-only logging) must not turn norm() into a collective."""
+        from . import distributed as Dm
+        if not across_ranks and group is None:
+            return Dm.LOCAL
+        if Dm._active(group):
+            # every rank has to hold one shard of ONE ensemble weighted with the global N (initial_conditions(ntraj_total=...))
+            count = torch.tensor([float(self.ntraj)], dtype=F64, device=self.device)
+            Dm.all_reduce_sum(count, group)
+            if int(round(float(count.item()))) != int(self._ntraj_norm):
+                raise ValueError(f"norm(across_ranks=True): the ranks hold {int(count.item())} trajectories together but the "
+                                 f"Monte-Carlo weight is 1/{self._ntraj_norm}: the ranks do not share one ensemble "
+                                 "(pass ntraj_total = the global count to initial_conditions, or take the rank-local norm())")
+        return group
+
+    def norm(self, across_ranks=False, group=None):
         """|psi| = sqrt(sum_ij v_i^* <q_i,p_i,Gamma_t|q_j,p_j,Gamma_t> v_j), O(n^2) (reference propagators.py:734-782).
 
         The pair sum runs in ``sc_pair_sum_rect``; the host only packs the operands: positions are centred (the overlaps
         depend on differences) so that the per-trajectory and the cross terms of the exponent stay small.
 
-        Across ranks (``torch.distributed`` initialised, every rank holding one shard of the ensemble with the global N as
-        ``ntraj_total``): the ket operands of all ranks are all-gathered, every rank sums ITS bras against ALL kets and
-        one all-reduce adds the partial sums -- every rank returns the norm of the whole wavefunction.
+        By default the norm of THIS rank's trajectories with this rank's weights (no communication).
+        ``across_ranks=True`` (or an explicit ``group``) -- every rank of the group holds one shard of one ensemble with
+        the global N as ``ntraj_total`` and every rank makes the call: the ket operands of all ranks are all-gathered,
+        every rank sums ITS bras against ALL kets and one all-reduce adds the partial sums -- every rank returns the norm
+        of the whole wavefunction.
         """
         from . import distributed as Dm
+        group = self._norm_group(across_ranks, group)
         dev, d, n = self.device, self.dim, self.ntraj
         oc = hostmath.OverlapConstants(self._Gt, self._Gt)
         A, B, Cm = (m.to(dev) for m in (oc.A, oc.B, oc.C))
@@ -886,10 +919,12 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
                                  self._stream()))
         return phi.cpu().numpy()
 
-    def norm(self, group=None):
-        """norm |psi| of the WM wavefunction, O(n^2) with a d' x d' inverse per pair (reference :1484-1575); across ranks as
-        HermanKlukPropagator.norm: every rank sums its bras against the all-gathered kets, one all-reduce"""
+    def norm(self, across_ranks=False, group=None):
+        """norm |psi| of the WM wavefunction, O(n^2) with a d' x d' inverse per pair (reference :1484-1575); rank-local by
+        default, across ranks (opt-in) as HermanKlukPropagator.norm: every rank sums its bras against the all-gathered
+        kets, one all-reduce"""
         from . import distributed as Dm
+        group = self._norm_group(across_ranks, group)
         dev, n, d = self.device, self.ntraj, self.dim
         coef, cqq, dvec = self._export()
         U = self._wm_bufs["U"]                                   # (D, d') real

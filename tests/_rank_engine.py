@@ -46,7 +46,9 @@ def main():
     assert float(slots[0, 4]) == rank + 1.0
     cauto, kic = prop.finalize_slots(slots, 0.0, dt, E0)
     # the O(n^2) diagnostic across ranks: own bras against the all-gathered kets, one all-reduce (every rank gets the whole norm)
-    norm = prop.norm() if os.environ.get("SC_TEST_NORM") else float("nan")
+    norm = prop.norm(across_ranks=True) if os.environ.get("SC_TEST_NORM") else float("nan")
+    # the default norm() is rank-local: called by ONE rank only it must neither hang nor see the other rank's kets
+    local_norm = prop.norm() if (os.environ.get("SC_TEST_NORM") and rank == 0) else float("nan")
     norms = [None] * world
     if world > 1:
         dist.all_gather_object(norms, norm)
@@ -54,7 +56,7 @@ def main():
         norms = [norm]
     if rank == 0:
         np.savez(out, cauto=cauto, kic=kic, world=world, backend=dist.get_backend() if world > 1 else "none",
-                 norms=np.array(norms, dtype=float))
+                 norms=np.array(norms, dtype=float), local_norm_rank0=local_norm)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

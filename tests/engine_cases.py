@@ -34,13 +34,15 @@ def engine_potential(g):
     raise ValueError(kind)
 
 
-def engine_propagator(g, device="cuda", **kwargs):
+def engine_propagator(g, device="cuda", select=None, ntraj_total=None, **kwargs):
+    """``select``: a slice of the fixture's trajectories (one rank's shard), ``ntraj_total``: the N of their weights"""
     from semiclassical_amd import propagators as PR
     Gi, Gt = cases.T(g["Gamma_i"]), cases.T(g["Gamma_t"])
     if "alpha" in g:
         prop = PR.WaltonManolopoulosPropagator(Gi, Gt, float(g["alpha"]), float(g["beta"]), device=device)
     else:
         prop = PR.HermanKlukPropagator(Gi, Gt, device=device, **kwargs)
+    sel = slice(None) if select is None else select
     prop.set_initial_conditions(cases.T(g["q0"]), cases.T(g["p0"]), cases.T(g["Gamma_0"]),
-                                cases.T(g["zi"]), cases.T(g["probi"]))
+                                cases.T(g["zi"][:, sel]), cases.T(g["probi"][sel]), ntraj_total=ntraj_total)
     return prop

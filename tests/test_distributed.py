@@ -130,8 +130,7 @@ def test_two_engine_ranks_on_one_gpu(case, tol, tmp_path):
     with_norm = case != "hk_as60"                # the O(n^2) norm of the small cases only
     rc = D.launch_local_ranks([os.path.join(ROOT, "tests", "_rank_engine.py"), case, str(nt), out], 2, timeout=600,
                               extra_env={"SC_DIST_BACKEND": "gloo", "SC_TEST_DEVICE": "0", "SC_TEST_NORM": "1" if with_norm else ""})
-    if rc != 0 and not os.path.exists(out):
-        pytest.fail(f"rank processes failed with exit code {rc}")
+    assert rc == 0, f"a rank process failed (largest exit code {rc})"        # a rank that dies AFTER the flush fails too
     r = np.load(out)
     assert int(r["world"]) == 2 and str(r["backend"]) == "gloo"
     assert cases.rel_err(r["cauto"], g["cauto"][:nt]) < tol
@@ -144,3 +143,98 @@ def test_two_engine_ranks_on_one_gpu(case, tol, tmp_path):
         whole.run(engine_potential(g), float(g["dt"]), nt, float(g["E0"]))
         want = whole.norm()
         assert r["norms"].shape == (2,) and np.all(np.abs(r["norms"] - want) < 1e-10 * want), (r["norms"], want)
+        # ... while the DEFAULT norm() stays rank-local although a process group exists (only rank 0 called it: a collective
+        # would have hung): the norm of rank 0's shard with the weights it carries
+        sl = D.shard_slice(g["zi"].shape[1], 0, 2)
+        part = engine_propagator(g, select=sl, ntraj_total=g["zi"].shape[1])
+        part.run(engine_potential(g), float(g["dt"]), nt, float(g["E0"]))
+        assert abs(float(r["local_norm_rank0"]) - part.norm()) < 1e-10 * part.norm()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prop,tol", [("HK", 1e-12), ("WM", 1e-12)])
+def test_two_ranks_through_the_driver(prop, tol, tmp_path):
+    """The product driver under a process group (north_star: trajectory batches shard across the GPUs, one all-reduce per
+    flush): two rank processes on cuda:0 run `run_semiclassical_dynamics` on the reference's methylium example task, each
+    on ITS half of every batch of the reference's sampled initial conditions; rank 0's correlations.npz must be the
+    reference driver's (tests/golden/driver_methylium.npz, cli.py:321-324, 374-476)."""
+    from semiclassical_amd import distributed as D
+    g = cases.load("driver_methylium")
+    out = str(tmp_path / "correlations.npz")
+    rc = D.launch_local_ranks([os.path.join(ROOT, "tests", "_rank_driver.py"), prop, out], 2, timeout=600,
+                              extra_env={"SC_DIST_BACKEND": "gloo", "SC_TEST_DEVICE": "0",
+                                         "SC_TEST_NORM_EVERY": "11" if prop == "HK" else ""})
+    assert rc == 0, f"a rank process failed (largest exit code {rc})"
+    got = dict(np.load(out))
+    assert int(got["trajectories"]) == 96 and str(got["propagator"]) == prop
+    assert np.array_equal(got["times"], g[f"{prop}_times"])
+    assert cases.rel_err(got["autocorrelation"], g[f"{prop}_autocorrelation"]) < tol
+    assert cases.rel_err(got["ic_correlation"], g[f"{prop}_ic_correlation"]) < tol
+
+
+@pytest.mark.gpu
+def test_rccl_flush_through_the_c_abi():
+    """sc_comm_* / sc_flush_allreduce bind librccl by themselves (no torch.distributed).  One GPU per box: a communicator
+    of ONE rank -- ncclGetUniqueId, ncclCommInitRank and ncclAllReduce(ncclDouble, ncclSum) really run on the device
+    and leave the sums of the only rank unchanged; the rank-local column survives."""
+    from semiclassical_amd import distributed as D
+    from semiclassical_amd._lib import lib
+    assert lib.sc_comm_available() > 0
+    dev = torch.device("cuda", 0)
+    comm = D.RcclCommunicator(0, 1, dev)
+    try:
+        assert comm.rank_count() == (0, 1)
+        slots = torch.rand((64, 5), dtype=torch.float64, device=dev)
+        want = slots.clone()
+        D.flush_correlations(slots, comm=comm)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(slots, want)
+        big = torch.rand(1 << 20, dtype=torch.float64, device=dev)
+        keep = big.clone()
+        comm.all_reduce_sum(big)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(big, keep)
+    finally:
+        comm.destroy()
+
+
+def test_comm_entry_points_reject_bad_arguments():
+    """no GPU needed: argument checks of the flush entry points (librccl itself is present in the image)"""
+    import ctypes
+    from semiclassical_amd._lib import lib
+    assert lib.sc_comm_available() > 0
+    assert lib.sc_flush_allreduce(None, 8, None, None) != 0
+    assert b"communicator" in lib.sc_last_error() or b"buffer" in lib.sc_last_error()
+    handle = ctypes.c_void_p()
+    assert lib.sc_comm_init(None, 2, 0, ctypes.byref(handle)) != 0
+    buf = ctypes.create_string_buffer(128)
+    assert lib.sc_comm_init(buf, 2, 5, ctypes.byref(handle)) != 0
+    assert lib.sc_comm_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_driver_flushes_through_the_c_abi_communicator(tmp_path):
+    """run_semiclassical_dynamics(task, comm=RcclCommunicator): the per-batch flush goes through sc_flush_allreduce (a
+    one-rank RCCL communicator on this box) and must leave the single-process result bit for bit."""
+    from semiclassical_amd import distributed as D, driver
+    g = cases.load("hk_as5_chi002")
+    model = tmp_path / "AS_model.dat"
+    rows = np.vstack((g["omega"] * 219474.63, 0.5 * g["omega"] * g["q0"] ** 2 * np.sign(g["q0"]), g["nac"],
+                      np.full(5, 0.02))).T
+    np.savetxt(model, rows)
+    res = []
+    for tag in ("plain", "rccl"):
+        out = tmp_path / f"{tag}.npz"
+        task = {"task": "dynamics", "potential": {"type": "anharmonic AS", "model_file": str(model)},
+                "propagator": "HK", "batch_size": 600, "num_trajectories": 1200, "num_steps": 16, "time_step_fs": 0.04,
+                "results": {"correlations": str(out)}, "manual_seed": 5}
+        comm = D.RcclCommunicator(0, 1, "cuda:0") if tag == "rccl" else None
+        try:
+            driver.run_semiclassical_dynamics(task, device="cuda:0", comm=comm)
+        finally:
+            if comm is not None:
+                comm.destroy()
+        res.append(dict(np.load(out)))
+    assert int(res[1]["trajectories"]) == 1200
+    assert np.array_equal(res[0]["autocorrelation"], res[1]["autocorrelation"])
+    assert np.array_equal(res[0]["ic_correlation"], res[1]["ic_correlation"])
