@@ -160,6 +160,12 @@ typedef struct sc_wm_consts {
      * (flags[n] counts them) and recomputed with full partial pivoting by the LDS kernel in the same call.  NULL: no
      * such re-run (the fixed-order result is used as it is). */
     int32_t *flags;
+    /* [n][3 D + 3] or NULL.  Position-dependent derivative couplings (potentials whose derivative_coupling_1st / _2nd
+     * depend on r; the reference evaluates them at the initial and the current points of every trajectory,
+     * propagators.py:1685-1693): per trajectory n1(q_i)[D], S n1(q_i)[D], G0 n1(Q)[D], p0.n1(Q), n2(q_i), n2(Q), filled by
+     * the caller before every call; they replace n1, s_n1, w_n1, p0n1, n2 above and route the call to the LDS / scratch
+     * kernels. */
+    const double *nac_traj;
 } sc_wm_consts;
 
 /* sGDML force field, reference semiclassical/gdml_predictor.py:57-85 (constructor) and :96-250 (forward).

@@ -53,7 +53,8 @@ class sc_wm_consts(C.Structure):
                 ("p0n1", C.c_double), ("n2", C.c_double),
                 ("detA", c_double_p), ("detM", c_double_p), ("sgnA", c_double_p), ("sgnM", c_double_p),
                 ("pre_coef", C.c_double), ("coef_out", c_double_p), ("cqq_out", c_double_p), ("dvec_out", c_double_p),
-                ("scratch", c_double_p), ("scratch_bytes", C.c_int64), ("flags", C.c_void_p)]
+                ("scratch", c_double_p), ("scratch_bytes", C.c_int64), ("flags", C.c_void_p),
+                ("nac_traj", c_double_p)]
 
 
 class sc_gdml_model(C.Structure):

@@ -138,6 +138,15 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
     double acc[4] = {0, 0, 0, 0};
 
     for (int64_t tr = blockIdx.x; tr < A.st.n && !idle; tr += gridDim.x) {
+        // coupling vectors: the constants of the reference potentials, or (position-dependent derivative couplings,
+        // sc_wm_consts.nac_traj) this trajectory's own n1(q_i), S n1(q_i), G0 n1(Q), p0.n1(Q), n2(q_i), n2(Q)
+        const double *tn1 = cn1, *tsn1 = csn1, *twn1 = cwn1;
+        double tp0n1 = W.p0n1, tn2q = W.n2, tn2Q = W.n2;
+        if (W.nac_traj) {
+            const double *blk = W.nac_traj + (size_t)tr * (3 * D + 3);
+            tn1 = blk; tsn1 = blk + D; twn1 = blk + 2 * D;
+            tp0n1 = blk[3 * D]; tn2q = blk[3 * D + 1]; tn2Q = blk[3 * D + 2];
+        }
         if (only && !only[tr]) continue;
         const double *qp = A.st.qp + tr * 2 * D, *zi = A.zi + tr * 2 * D;
         const double *M = A.st.mono + tr * 4 * (int64_t)DD;
@@ -223,14 +232,14 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             cplx y = c_make(qp[D + a] - cp0[a], 0.0), u1 = c_make(0, 0), u2 = c_make(0, 0);
             for (int b = 0; b < D; ++b) {
                 const cplx gt = Gti[a * D + b];
-                const double g = vec[3 * D + b], s1 = vec[4 * D + b], s2 = A.has_nac ? csn1[b] : 0.0;
+                const double g = vec[3 * D + b], s1 = vec[4 * D + b], s2 = A.has_nac ? tsn1[b] : 0.0;
                 y.x = fma(gt.x, g, y.x); y.y = fma(gt.y, g, y.y);
                 u1.x = fma(gt.x, s1, u1.x); u1.y = fma(gt.y, s1, u1.y);
                 u2.x = fma(gt.x, s2, u2.x); u2.y = fma(gt.y, s2, u2.y);
             }
             cv[a] = u1; cv[D + a] = u2;
             cv[2 * D + a] = c_make(vec[5 * D + a], 0.0);
-            cv[3 * D + a] = c_make(A.has_nac ? cwn1[a] : 0.0, 0.0);
+            cv[3 * D + a] = c_make(A.has_nac ? twn1[a] : 0.0, 0.0);
             cv[4 * D + a] = y;
         }
         __syncthreads();
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             double cdq = 0.0, cn1v = 0.0, g0g = 0.0;
             for (int b = 0; b < D; ++b) {
                 cdq = fma(cCqq[a * D + b], vec[b], cdq);
-                if (A.has_nac) cn1v = fma(cCqq[a * D + b], cn1[b], cn1v);
+                if (A.has_nac) cn1v = fma(cCqq[a * D + b], tn1[b], cn1v);
                 g0g = fma(cG0[a * D + b], vec[3 * D + b], g0g);
             }
             rowtmp[a] = cdq; rowtmp[D + a] = cn1v; rowtmp[2 * D + a] = g0g;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
                 dqCdq = fma(vec[a], cdq, dqCdq);
                 dqCn1 = fma(vec[a], crow, dqCn1);
                 dQGdQ = fma(vec[D + a], vec[5 * D + a], dQGdQ);
-                if (A.has_nac) { dQGn1 = fma(vec[D + a], cwn1[a], dQGn1); piq_n1 = fma(piq, cn1[a], piq_n1); }
+                if (A.has_nac) { dQGn1 = fma(vec[D + a], twn1[a], dQGn1); piq_n1 = fma(piq, tn1[a], piq_n1); }
                 piq_dq = fma(piq, vec[a], piq_dq);
                 p0_dQ = fma(cp0[a], vec[D + a], p0_dQ);
                 eps = fma(vec[2 * D + a], vec[3 * D + a], eps);
@@ -351,16 +360,16 @@ __global__ __launch_bounds__(256) void wm_kernel(WmArgs A) {
             }
             if (A.has_nac) {
                 const cplx nacqQ = form(UN1, WN1);
-                const cplx PQ_n1 = c_add(c_make(W.p0n1, 0), form(WN1, Y));
+                const cplx PQ_n1 = c_add(c_make(tp0n1, 0), form(WN1, Y));
                 const cplx Pq_n1 = c_sub(c_make(piq_n1, 0), form(UN1, Y));
                 cplx nacQ = c_sub(c_make(dQGn1, 0), form(WDQ, WN1));                // dQ^T RQQ n1
                 nacQ = c_sub(nacQ, form(UDQ, WN1));                                 // - dq^T RqQ n1
                 nacQ = c_add(nacQ, c_mul(c_make(0.0, -ihb), PQ_n1));
-                nacQ.x += W.n2;
+                nacQ.x += tn2Q;
                 cplx nacq = c_sub(c_make(dqCn1, 0), form(UDQ, UN1));                // dq^T Rqq n1
                 nacq = c_sub(nacq, form(UN1, WDQ));                                 // - n1^T RqQ dQ
                 nacq = c_add(nacq, c_mul(c_make(0.0, ihb), Pq_n1));
-                nacq.x += W.n2;
+                nacq.x += tn2q;
                 cplx kq = c_mul(c_add(nacqQ, c_mul(nacQ, nacq)), cq);               // (100)
                 kq = c_scale(kq, ihb * ihb);
                 acc[2] += kq.x; acc[3] += kq.y;
@@ -610,7 +619,7 @@ extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const
         hipLaunchKernelGGL(wm_kernel<false>, dim3(nblocks), dim3(threads), bytes, s, a);
         return sc_check_launch("sc_wm_correlate");
     };
-    if (wm_has_small_kernel(D, dp)) {
+    if (wm_has_small_kernel(D, dp) && !wc->nac_traj) {          // per-trajectory coupling vectors: the general kernel
         if (!wc->scratch || wc->scratch_bytes < sc_wm_scratch_bytes(st->n, D, dp))
             return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: D=%d d'=%d needs a scratch buffer of %lld B (sc_wm_scratch_bytes), "
                            "got %lld", D, dp, (long long)sc_wm_scratch_bytes(st->n, D, dp), (long long)wc->scratch_bytes);

@@ -41,13 +41,22 @@ def _potential_fingerprint(potential):
     Caches are keyed on the object itself (a strong reference, compared with ``is``: a recycled ``id`` cannot alias a
     dead potential) AND on this cheap content fingerprint, so that masses or coupling vectors changed in place are
     picked up at the next step / run entry.  O(D) host work per call.
+
+    The derivative couplings are probed at TWO points.  The reference evaluates them at the initial and the current
+    position of every trajectory (propagators.py:880-892, 1685-1693); all of its own potentials return constant vectors,
+    which the kernels take as constants.  A potential whose couplings differ between the probes is position dependent:
+    the last entry of the fingerprint says so and the propagators evaluate its couplings per trajectory.
     """
     d = potential.dimensions()
     probe = torch.zeros((d, 1), dtype=F64)
+    other = (0.05 + 0.1 * torch.arange(1, d + 1, dtype=F64) / d).reshape(d, 1)
     masses = hostmath.as_f64(potential.masses())
     tau1 = hostmath.as_f64(potential.derivative_coupling_1st(probe))[:, 0]
     tau2 = hostmath.as_f64(potential.derivative_coupling_2nd(probe))[:, 0]
-    return masses, tau1, tau2
+    tau1b = hostmath.as_f64(potential.derivative_coupling_1st(other))[:, 0]
+    tau2b = hostmath.as_f64(potential.derivative_coupling_2nd(other))[:, 0]
+    varies = not (torch.equal(tau1, tau1b) and torch.equal(tau2, tau2b))
+    return masses, tau1, tau2, torch.tensor([float(varies)], dtype=F64)
 
 
 def _same_fingerprint(a, b):
@@ -82,7 +91,7 @@ class HermanKlukPropagator(object):
         self.Gamma_i, self.Gamma_t = Gamma_i.to(self.device), Gamma_t.to(self.device)
         self.sqGi, self.isqGi = hostmath.sym_sqrtm(Gamma_i)
         self.sqGt, self.isqGt = hostmath.sym_sqrtm(Gamma_t)
-        self._nac, self._nac_pot, self._nac_fp = None, None, None
+        self._nac, self._nac_pot, self._nac_fp, self._nac_generic = None, None, None, None
         self._ntraj_norm = None
 
     # ------------------------------------------------------------------ initial conditions
@@ -201,7 +210,7 @@ class HermanKlukPropagator(object):
         self._elog = torch.zeros(4, dtype=F64, device=dev)            # energy guard log (sc_energy_guard)
         self._nsteps = 0
         self._corr_step, self._corr_has_nac = -1, False
-        self._nac, self._nac_pot, self._nac_fp = None, None, None
+        self._nac, self._nac_pot, self._nac_fp, self._nac_generic = None, None, None, None
         self._dense = None
         # diagonals of the monodromy blocks for the separable shortcut; _mono is stale while they are ahead of it
         self._mdiag = torch.zeros((n, 4, d), dtype=F64, device=dev)
@@ -447,16 +456,54 @@ class HermanKlukPropagator(object):
         current, fp = self._nac_is_current(potential)
         if current:
             return
-        masses, tau1, tau2 = fp
+        masses, tau1, tau2, varies = fp
+        dev = self.device
+        self._nac_pot, self._nac_fp = potential, tuple(x.clone() for x in fp)
+        self._corr_step = -1
+        if bool(varies.item()):
+            # position-dependent couplings: evaluated per trajectory by the potential's own torch code (_nac_terms)
+            self._nac, self._nac_bufs, self._nacq = None, None, None
+            G = self._G0h @ self._iGi0h
+            self._nac_generic = {"minv": (1.0 / masses).to(dev).unsqueeze(1), "R": (G @ self._Gi).to(dev), "G": G.to(dev)}
+            self._nac_generic["initial"] = self._nac_terms(potential, self.zi[:self.dim], self.zi[self.dim:], sign=+1.0)
+            return
+        self._nac_generic = None
         nc = hostmath.NacConstants(self._G0h, self._Gi, self._iGi0h, self._p0h, masses, tau1,
                                    tau2_sum=float(torch.sum(tau2 / masses)))
-        dev = self.device
         bufs = [nc.rn.to(dev), nc.gn.to(dev)]
         self._nac = sc_nac_consts(dim=self.dim, rn=ptr(bufs[0]), gn=ptr(bufs[1]), q0=ptr(self.q0), p0=ptr(self.p0),
                                   p0n1=nc.p0n1, n2=nc.n2)
-        self._nac_bufs, self._nac_pot, self._nac_fp = bufs, potential, tuple(x.clone() for x in fp)
+        self._nac_bufs = bufs
         self._nacq = torch.zeros(self.ntraj, dtype=C128, device=dev)
         check(lib.sc_nac_initial(self._nac, ptr(self._zi_t), self.ntraj, ptr(self._nacq), self._stream()))
+
+    def _coupling_vectors(self, potential, r):
+        """n1 (D, n) and n2 (n,) of eqns (89), (90) at the positions r (D, n) on the device, reference propagators.py:880-892"""
+        c = self._nac_generic
+        tau1 = potential.derivative_coupling_1st(r).to(F64)
+        tau2 = potential.derivative_coupling_2nd(r).to(F64)
+        assert tau1.shape == r.shape and tau2.shape == r.shape, "derivative couplings have to be of shape (D, n)"
+        return -hbar ** 2 * c["minv"] * tau1, -hbar ** 2 * 0.5 * torch.sum(c["minv"] * tau2, dim=0)
+
+    def _nac_terms(self, potential, r, mom, sign):
+        """nacq (sign = +1, initial points) or nacQ (sign = -1, current points) of propagators.py:894-903 for
+        position-dependent couplings, (n,) complex on the device"""
+        c = self._nac_generic
+        n1, n2 = self._coupling_vectors(potential, r)
+        PI = self.p0.unsqueeze(1) + c["G"] @ (mom - self.p0.unsqueeze(1))
+        real = n2 + torch.sum((self.q0.unsqueeze(1) - r) * (c["R"] @ n1), dim=0)
+        return torch.complex(real, sign / hbar * torch.sum(PI * n1, dim=0))
+
+    def _generic_kic(self, slot_row):
+        """k_ic sum of the current state for position-dependent couplings into slot_row[2:4] (device, no host sync):
+        sum_i nacQ_i nacq_i cq_i / hbar^2 with the per-trajectory C_auto terms the correlate kernel just wrote"""
+        c = self._nac_generic
+        qp = self._qp.t()
+        nacQ = self._nac_terms(self._nac_pot, qp[:self.dim], qp[self.dim:], sign=-1.0)
+        kq = nacQ * c["initial"] * self._cq / hbar ** 2
+        self._kq.copy_(kq)
+        total = torch.sum(kq)
+        slot_row[2:4] = torch.view_as_real(total)
 
     def _mc_norm(self):
         return self._ntraj_norm * (2 * np.pi * hbar) ** self.dim
@@ -468,22 +515,28 @@ class HermanKlukPropagator(object):
         else:
             check(lib.sc_reduce_slot_at(ptr(partials), count, C_void(slot_ptr), ptr(cursor), self._stream()))
 
-    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None):
-        """per-trajectory terms + their sums for the current state into the 5-double slot at `slot_ptr`"""
+    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None, slot_row=None):
+        """per-trajectory terms + their sums for the current state into the 5-double slot at `slot_ptr` (`slot_row`: the same
+        five doubles as a tensor, needed when the k_ic sum is formed by torch: position-dependent couplings)"""
         s = self._stream()
         nac = self._nac
+        generic = getattr(self, "_nac_generic", None) is not None
+        per_trajectory = per_trajectory or generic
         with self._timed("hk_correlate"):
             check(lib.sc_hk_correlate(self._state, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
                                       ptr(self._nacq) if nac is not None else None, self._mc_norm(),
                                       ptr(self._cq) if per_trajectory else None,
                                       ptr(self._kq) if per_trajectory else None, ptr(self._cpart), s))
         self._reduce_into(self._cpart, self._gcorr, slot_ptr, cursor)
+        if generic:
+            assert slot_row is not None and cursor is None
+            self._generic_kic(slot_row)
 
     def _correlate_current(self, need_nac):
         if self._corr_step == self._nsteps and (self._corr_has_nac or not need_nac):
             return
-        self._launch_correlate(self._slot.data_ptr())
-        self._corr_step, self._corr_has_nac = self._nsteps, self._nac is not None
+        self._launch_correlate(self._slot.data_ptr(), slot_row=self._slot)
+        self._corr_step, self._corr_has_nac = self._nsteps, (self._nac is not None or self._nac_generic is not None)
         self._slot_host = self._slot.cpu().numpy().copy()          # host sync
         self._check_energy_guard()
 
@@ -527,7 +580,8 @@ class HermanKlukPropagator(object):
             self._check_slots(slots, nt)
         t0 = self.t
         base = slots.data_ptr()
-        fused = hasattr(potential, "_descriptor") and not hasattr(potential, "_gdml_model") and self.dim <= 64
+        fused = (hasattr(potential, "_descriptor") and not hasattr(potential, "_gdml_model") and self.dim <= 64
+                 and self._nac_generic is None)
         desc = self._potential_descriptor(potential, dt) if fused else None
         if fused and self._whole_loop_applies(desc):
             # separable potential, diagonal widths, D <= 12: the whole loop as ONE launch (sc_hk_run)
@@ -536,7 +590,7 @@ class HermanKlukPropagator(object):
             self._run_graph(potential, dt, nt, desc, slots)
         else:
             for k in range(nt):
-                self._launch_correlate(base + 40 * k, per_trajectory=False)
+                self._launch_correlate(base + 40 * k, per_trajectory=False, slot_row=slots[k])
                 self._launch_step(potential, dt, desc=desc, remembered=True)
                 self.t += dt
         self._corr_step = -1
@@ -844,7 +898,7 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         self._wpart = torch.zeros((self._gwm, 4), dtype=F64, device=dev)
         self._wm_step, self._wm_has_nac = -1, False
         self._wm_export_step = -1
-        self._wm_nac_bufs = None
+        self._wm_nac_bufs, self._wm_nac_traj = None, None
         need = lib.sc_wm_scratch_bytes(n, self.dim, wm.dprime)      # 0 while the matrices of a trajectory fit on chip
         assert need >= 0
         self._wm_scratch = torch.empty(need // 8, dtype=F64, device=dev) if need > 0 else None
@@ -860,24 +914,52 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
             p0n1=self._wm_p0n1 if nb else 0.0, n2=self._wm_n2 if nb else 0.0,
             detA=ptr(self._detA), detM=ptr(self._detM), sgnA=ptr(self._sgnA), sgnM=ptr(self._sgnM),
             pre_coef=wm.pre_coef, scratch=ptr(self._wm_scratch),
-            scratch_bytes=0 if self._wm_scratch is None else self._wm_scratch.numel() * 8, flags=ptr(self._wm_flags))
+            scratch_bytes=0 if self._wm_scratch is None else self._wm_scratch.numel() * 8, flags=ptr(self._wm_flags),
+            nac_traj=ptr(getattr(self, "_wm_nac_traj", None)))
 
     def _remember_nac(self, potential):
         current, fp = self._nac_is_current(potential)
         if current:
             return
         super()._remember_nac(potential)
-        masses, tau1, tau2 = fp
-        n1 = -hbar ** 2 * tau1 / masses
+        masses, tau1, tau2, varies = fp
         wm = self._wm_host
         dev = self.device
+        if bool(varies.item()):
+            # position-dependent couplings: per trajectory n1(q_i), S n1(q_i), G0 n1(Q), p0.n1(Q), n2(q_i), n2(Q)
+            # (sc_wm_consts.nac_traj); the q_i part is filled once, the Q part before every launch (_refresh_nac_traj)
+            d, n = self.dim, self.ntraj
+            self._wm_S, self._wm_G0 = wm.S.to(dev), wm.G0.to(dev)
+            blk = torch.zeros((n, 3 * d + 3), dtype=F64, device=dev)
+            n1q, n2q = self._coupling_vectors(potential, self.zi[:d])
+            blk[:, :d] = n1q.t()
+            blk[:, d:2 * d] = (self._wm_S @ n1q).t()
+            blk[:, 3 * d + 1] = n2q
+            self._wm_nac_traj = blk
+            self._wm_nac_bufs = None
+            self._build_wm_struct()
+            return
+        self._wm_nac_traj = None
+        n1 = -hbar ** 2 * tau1 / masses
         self._wm_nac_bufs = [n1.to(dev), (wm.S @ n1).to(dev), (wm.G0 @ n1).to(dev)]
         self._wm_p0n1 = float(torch.dot(self._p0h, n1))
         self._wm_n2 = float(-hbar ** 2 * 0.5 * torch.sum(tau2 / masses))
         self._build_wm_struct()
 
+    def _refresh_nac_traj(self):
+        """the current-point half of sc_wm_consts.nac_traj: G0 n1(Q), p0.n1(Q), n2(Q) (reference propagators.py:1689-1697)"""
+        d = self.dim
+        n1Q, n2Q = self._coupling_vectors(self._nac_pot, self._qp.t()[:d])
+        blk = self._wm_nac_traj
+        blk[:, 2 * d:3 * d] = (self._wm_G0 @ n1Q).t()
+        blk[:, 3 * d] = self.p0 @ n1Q
+        blk[:, 3 * d + 2] = n2Q
+
     def _wm_launch(self, track):
-        has_nac = self._wm_nac_bufs is not None
+        traj = getattr(self, "_wm_nac_traj", None)
+        has_nac = self._wm_nac_bufs is not None or traj is not None
+        if traj is not None:
+            self._refresh_nac_traj()
         with self._timed("wm"):
             check(lib.sc_wm_correlate(self._state, self._wm, ptr(self._zi_t), ptr(self.probi), self._mc_norm(),
                                       track, int(has_nac), ptr(self._cq), ptr(self._kq), ptr(self._wpart),
@@ -948,10 +1030,11 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
         Dm.all_reduce_sum(slot, group)
         return float(torch.sqrt(slot[0]).item())
 
-    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None):
+    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None, slot_row=None):
         # the per-trajectory terms were produced together with the prefactor; recompute (with the stored branch
         # signs, no tracking) only if the coupling vector was not known at that time
-        if self._wm_step != self._nsteps or (self._wm_nac_bufs is not None and not self._wm_has_nac):
+        knows_nac = self._wm_nac_bufs is not None or self._wm_nac_traj is not None
+        if self._wm_step != self._nsteps or (knows_nac and not self._wm_has_nac):
             self._wm_launch(0)
         self._reduce_into(self._wpart, self._gwm, slot_ptr, cursor)
 

@@ -238,3 +238,17 @@ def test_driver_flushes_through_the_c_abi_communicator(tmp_path):
     assert int(res[1]["trajectories"]) == 1200
     assert np.array_equal(res[0]["autocorrelation"], res[1]["autocorrelation"])
     assert np.array_equal(res[0]["ic_correlation"], res[1]["ic_correlation"])
+
+
+@pytest.mark.gpu
+def test_torch_nccl_backend_on_the_visible_gpus(tmp_path):
+    """the transport bench.py / the driver use for N > 1 -- torch.distributed's `nccl` backend, which is RCCL on ROCm -- forms
+    a process group over every GPU this box shows (one per process; a single rank on the one-GPU test boxes) and
+    all-reduces a slot buffer on the device"""
+    from semiclassical_amd import distributed as D
+    n = min(torch.cuda.device_count(), 6)
+    out = tmp_path / "nccl.json"
+    rc = D.launch_local_ranks([os.path.join(ROOT, "tests", "_rank_nccl.py"), str(out)], n, timeout=300)
+    assert rc == 0
+    r = json.loads(out.read_text())
+    assert r["backend"] == "nccl" and r["world"] == n and r["ok"]

@@ -109,3 +109,110 @@ def test_more_than_64_dimensions_through_the_dense_path(D, dense_gamma):
     c, k = prop.run(P.MorsePotential(omega, chi.clone(), nac), dt, nt, E0)
     assert cases.rel_err(prop.y.cpu().numpy(), ref.y.numpy()) < 1e-9
     assert cases.rel_err(c, rc) < 1e-8 and cases.rel_err(k, rk) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# position-dependent derivative couplings (reference propagators.py:880-903, 1685-1714: the couplings are evaluated at
+# the initial AND the current points of every trajectory; the reference's own potentials return constants)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _varying_tau1(nac, r):
+    """tau1_a(r) = nac_a (1 + 0.4 r_a + 0.15 r_{a+1} + 0.05 r_a^2): changes along every trajectory"""
+    nac = nac.to(r.device).unsqueeze(1)
+    return nac * (1.0 + 0.4 * r + 0.15 * torch.roll(r, -1, dims=0) + 0.05 * r * r)
+
+
+def _varying_tau2(nac, r):
+    nac = nac.to(r.device).unsqueeze(1)
+    return nac * (0.4 + 0.1 * r) * 1e-2
+
+
+class QuarticWithVaryingCoupling(CoupledQuarticPotential):
+    def derivative_coupling_1st(self, r):
+        return _varying_tau1(self.nac, r)
+
+    def derivative_coupling_2nd(self, r):
+        return _varying_tau2(self.nac, r)
+
+
+@pytest.mark.parametrize("kind", ["HK", "WM"])
+@pytest.mark.parametrize("surface", ["generic", "morse", "harmonic-dense"])
+def test_position_dependent_couplings_match_oracle(kind, surface):
+    """k_ic(t) with couplings that depend on the position, against the oracle driving the same coupling functions: a generic
+    Python surface (unfused step), the Morse surface (fused separable step kernel, whole-loop / graph paths must stand
+    back) and the constant-Hessian molecular surface (register kernels; WM must leave wm_small_kernel for the kernel that
+    takes per-trajectory coupling vectors)."""
+    from oracle import sc_oracle as orc
+    from semiclassical_amd import potentials as P, propagators as PR
+    rng = np.random.default_rng(33)
+    D, n, nt, dt = 5, 150, 12, 1.5
+    omega = torch.from_numpy(np.sort(rng.uniform(700, 2600, D)) / 219474.63)
+    nac = torch.from_numpy(rng.normal(0, 1e-3, D))
+    if surface == "generic":
+        masses = torch.from_numpy(rng.uniform(0.8, 1.6, D))
+        pot = ref_pot = QuarticWithVaryingCoupling(omega, 2.0e-6, masses, nac)
+        G = torch.diag(omega * masses)
+        q0 = torch.from_numpy(rng.uniform(-6.0, 6.0, D))
+    elif surface == "morse":
+        chi = torch.full((D,), 0.02)
+
+        class Eng(P.MorsePotential):
+            def derivative_coupling_1st(self, r):
+                return _varying_tau1(nac, r)
+
+            def derivative_coupling_2nd(self, r):
+                return _varying_tau2(nac, r)
+
+        class Orc(orc.MorseOracle):
+            def derivative_coupling_1st(self, r):
+                return _varying_tau1(nac, r)
+
+            def derivative_coupling_2nd(self, r):
+                return _varying_tau2(nac, r)
+        pot, ref_pot = Eng(omega, chi.clone(), nac), Orc(omega, chi.clone(), nac)
+        G = torch.diag(omega)
+        q0 = torch.from_numpy(rng.uniform(-6.0, 6.0, D))
+    else:
+        g = cases.load("wm_methylium" if kind == "WM" else "hk_methylium")
+        D, dt = 12, float(g["dt"])
+        nac = cases.T(g["nac0"])
+        args = (g["pos0"], g["energy0"], g["grad0"], g["hess0"], g["masses"], g["nac0"])
+
+        class Eng(P.MolecularHarmonicPotential):
+            def derivative_coupling_1st(self, r):
+                return _varying_tau1(nac, r)
+
+            def derivative_coupling_2nd(self, r):
+                return _varying_tau2(nac, r)
+
+        class Orc(orc.MolecularHarmonicOracle):
+            def derivative_coupling_1st(self, r):
+                return _varying_tau1(nac, r)
+
+            def derivative_coupling_2nd(self, r):
+                return _varying_tau2(nac, r)
+        pot = Eng.from_arrays(*args, origin=float(g["origin"]))
+        ref_pot = Orc(*args, origin=float(g["origin"]))
+        G = cases.T(g["Gamma_i"])
+        q0 = cases.T(g["q0"])
+        n = 96
+    p0 = 0.0 * q0
+    E0 = 0.01
+    G0 = cases.T(g["Gamma_0"]) if surface == "harmonic-dense" else G
+    if kind == "HK":
+        ref, prop = orc.HKOracle(G, G), PR.HermanKlukPropagator(G, G, device="cuda")
+    else:
+        ab = 1.0e4 if surface == "harmonic-dense" else 80.0
+        ref, prop = orc.WMOracle(G, G, ab, ab), PR.WaltonManolopoulosPropagator(G, G, ab, ab, device="cuda")
+    torch.manual_seed(4)
+    ref.initial_conditions(q0, p0, G0, ntraj=n)
+    rc, rk = orc.run_loop(ref, ref_pot, dt, nt, E0)
+    prop.set_initial_conditions(q0, p0, G0, ref.zi, ref.probi)
+    c, k = prop.run(pot, dt, nt, E0)
+    assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-8, (cases.rel_err(c, rc), cases.rel_err(k, rk))
+    # ... and the step-at-a-time API gives the same numbers as run()
+    prop.set_initial_conditions(q0, p0, G0, ref.zi, ref.probi)
+    for t in range(3):
+        assert abs(prop.autocorrelation(E0) - rc[t]) < 1e-9 * abs(rc[t]) + 1e-14
+        assert abs(prop.ic_correlation(pot, E0) - rk[t]) < 1e-8 * np.abs(rk).max()
+        prop.step(pot, dt)
