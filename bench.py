@@ -32,6 +32,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 HBM_PEAK_GBS = 8000.0     # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet, vector = matrix FP64 (the guide gives no FP64 figure)
+# what the two FP64 pipes SUSTAIN on this pool's boxes (micro-benchmarks, profiles/): back-to-back v_fmac_f64 on 16 independent
+# accumulators, two waves per SIMD (r3_dpp_fmac.txt: 57-61 TFLOP/s), back-to-back v_mfma_f64_16x16x4_f64 (r4_mfma_f64.txt: 77)
+FP64_VALU_SUSTAINED_TFLOPS = 59.0
+FP64_MFMA_SUSTAINED_TFLOPS = 77.0
 
 
 def as60_model(dim=60):
@@ -59,17 +63,47 @@ def wm_flops_per_traj_step(D, dp):
     return 2 * fma
 
 
-def profiled_traffic(n, dim):
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/), if they match this workload"""
-    for name in ("r3_hbm_traffic.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json"):
+def profiled_traffic(n, dim, live_ms):
+    """HBM bytes per step-kernel launch from the newest committed rocprofv3 PMC passes (profiles/rN_hbm_traffic.json) --
+    but only if that profile still describes THIS run: same workload, same kernel, and the kernel-trace summary of the same
+    profiling session (profiles/rN_bench_kernel_stats.csv) gives the launch pair (step kernel + modes pre-pass) within 5 % of
+    the duration measured live (``live_ms``).  Otherwise (None, reason): a stale constant must not pose as a measurement."""
+    import csv
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")),
+                   key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)), reverse=True)
+    reasons = []
+    for path in files:
+        name = os.path.basename(path)
+        tag = name.split("_")[0]
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
+            with open(path) as f:
                 t = json.load(f)
-            if t["workload"]["ntraj"] == n and t["workload"]["dim"] == dim:
-                return t["traffic_bytes_per_launch"], f"profiles/{name} (FETCH_SIZE calibrated + WRITE_SIZE, separate passes)"
-        except (OSError, KeyError, ValueError):
+            if t["workload"]["ntraj"] != n or t["workload"]["dim"] != dim:
+                continue
+            kernel = t["workload"]["kernel"]
+            if "hk_step_sd_kernel<4, 4, true, true>" not in kernel:
+                reasons.append(f"profiles/{name} profiled {kernel}, not the kernel of this run")
+                continue
+            stats = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv")
+            avg = {}
+            with open(stats) as f:
+                for row in csv.reader(f):
+                    if len(row) >= 4 and row[0] != "Name" and not row[0].startswith("#"):
+                        avg[row[0]] = float(row[3]) / 1e3
+            step = next(v for k, v in avg.items() if "hk_step_sd_kernel<4, 4, true, true>" in k)
+            modes = next(v for k, v in avg.items() if "hk_modes_kernel" in k)
+            if abs(step + modes - live_ms) > 0.05 * live_ms:
+                reasons.append(f"profiles/{name}: its session measured {step + modes:.3f} ms per launch pair, this run {live_ms:.3f} ms "
+                          "(more than 5 % apart: the profile is stale for this build or box)")
+                continue
+            return t["traffic_bytes_per_launch"], (f"profiles/{name} (FETCH_SIZE calibrated + WRITE_SIZE, separate passes; kernel-trace of "
+                                                   f"that session: {step + modes:.3f} ms per launch pair, this run {live_ms:.3f} ms)")
+        except (OSError, KeyError, ValueError, StopIteration) as err:
+            reasons.append(f"profiles/{name}: {type(err).__name__} {err}")
             continue
-    return None, None
+    return None, (reasons[0] if reasons else "no profiles/rN_hbm_traffic.json for this workload")
 
 
 def cpu_baseline(omega, chi, nac, q0, dt, n=2000, nt=4):
@@ -174,10 +208,10 @@ def config1(dev, n, steps):
     out = {"workload": f"anharmonic-AS 5-mode, HK, n={n} (BASELINE.json configs[0])", "n": n, "steps": steps,
            "ms_per_step": wall / steps * 1e3, "value": n * steps / wall, "unit": "trajectory-steps/s",
            "kernel": "hk_run_sep16_kernel<8,MORSE>: the caller loop (C_auto, k_ic, step) x steps in one launch, state in registers",
-           "roofline": {"bound": "hbm", "achieved": nbytes / (wall / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": nbytes / (wall / steps) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes,
-                        "note": "algorithmic bytes of a step-at-a-time engine (SURVEY 8d) over the time per step of the whole-loop "
-                                "launch, which reads and writes a trajectory once per run() -- not an HBM measurement"}}
+           "equivalent_stepwise_GBps": nbytes / (wall / steps) / 1e9,
+           "equivalent_stepwise_note": "algorithmic bytes of a step-at-a-time engine (SURVEY 8d) over the time per step of the "
+                                       "whole-loop launch -- NOT achieved bandwidth: the launch reads and writes a trajectory once per "
+                                       "run(); what bounds it is FP64 VALU issue and latency (profiles/r3_config1_pmc.json)"}
     # the same loop step by step (six launches per step), eager and replayed from a HIP graph
     prop._whole_loop_ok = False
     wall_s = _timed_loop(prop, pot, dt, E0, steps, dev)
@@ -212,6 +246,8 @@ def config3(dev, n, steps):
             "kernels_ms": {"wm_small_kernel<12,6>": wm_ms, "hk_step_lin_kernel<12,6,false> (RK4 + HK prefactor)": hk_ms},
             "roofline": {"kernel": "wm_small_kernel<12,6>", "bound": "fp64", "achieved": flops / (wm_ms * 1e-3) / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / (wm_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "measured_pipe_rate": FP64_VALU_SUSTAINED_TFLOPS,
+                         "frac_of_measured_pipe_rate": flops / (wm_ms * 1e-3) / 1e12 / FP64_VALU_SUSTAINED_TFLOPS,
                          "algorithmic_flops_per_launch": flops,
                          "hbm_GBps": nbytes / (wm_ms * 1e-3) / 1e9, "hbm_frac": nbytes / (wm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "hk_step_roofline": {"bound": "hbm", "achieved": algorithmic_bytes_per_traj_step(D) * n / (hk_ms * 1e-3) / 1e9,
@@ -276,11 +312,16 @@ def config5(dev, n, steps):
                            "dense_mono_mfma_slab_kernel (difference)": k["dense_mono_step"] - pref_ms},
             "roofline": {"kernel": "gdml_stage_kernel", "bound": "fp64", "achieved": stage_flops / (k["gdml_stage"] * 1e-3) / 1e12,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": stage_flops / (k["gdml_stage"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                         "measured_pipe_rate": FP64_VALU_SUSTAINED_TFLOPS,
+                         "frac_of_measured_pipe_rate": stage_flops / (k["gdml_stage"] * 1e-3) / 1e12 / FP64_VALU_SUSTAINED_TFLOPS,
                          "algorithmic_flops_per_launch": stage_flops},
             "dense_mono_roofline": {"kernel": "dense_mono_mfma_slab_kernel", "bound": "fp64 (MFMA)",
                                     "achieved": mono_flops / ((k["dense_mono_step"] - pref_ms) * 1e-3) / 1e12,
                                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": mono_flops / ((k["dense_mono_step"] - pref_ms) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}}
+                                    "frac": mono_flops / ((k["dense_mono_step"] - pref_ms) * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                    "measured_pipe_rate": FP64_MFMA_SUSTAINED_TFLOPS,
+                                    "frac_of_measured_pipe_rate": mono_flops / ((k["dense_mono_step"] - pref_ms) * 1e-3) / 1e12
+                                                                  / FP64_MFMA_SUSTAINED_TFLOPS}}
 
 
 def other_configs(dev):
@@ -290,7 +331,9 @@ def other_configs(dev):
                           ("config5_gdml30_share", config5, (1250, 5)), ("config5_gdml30_n10000", config5, (10000, 3))):
         try:
             out[key] = fn(dev, *args)
-        except Exception as err:                      # a broken side measurement must not take the headline line down
+        except Exception as err:      # the headline line is still printed -- and the process then exits non-zero (main)
+            import traceback
+            traceback.print_exc(file=sys.stderr)
             out[key] = {"error": f"{type(err).__name__}: {err}"}
         torch.cuda.empty_cache()
     return out
@@ -310,8 +353,20 @@ def wall_to_full_ct(pot, omega, q0, dt, E0, n, dev, nt=2000):
     cauto, kic = prop.run(pot, dt, nt, E0)
     wall = time.perf_counter() - t0
     assert np.isfinite(cauto).all() and np.isfinite(kic).all() and abs(cauto[0] - 1.0) < 1e-3
+    # How converged is that C(t)?  The reference has no criterion (its only diagnostic is the O(n^2) norm, cli.py:424-429);
+    # C(t) is a Monte-Carlo mean, so its statistical error is the yardstick: with c_i the weighted per-trajectory terms
+    # (C = sum_i c_i), the standard error of the sum is sqrt(N sum_i |c_i|^2 - |C|^2) / sqrt(N - 1)  (outside the timed region).
+    prop._correlate_current(False)
+    ci = prop._cq
+    total = torch.sum(ci)
+    se = float(torch.sqrt(torch.clamp(n * torch.sum(torch.abs(ci) ** 2) - torch.abs(total) ** 2, min=0.0) / (n - 1)).item())
     return {"value": wall, "unit": "s", "steps": nt, "trajectories": n, "initial_conditions_s": t1 - t0,
-            "loop_s": wall - (t1 - t0), "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)]}
+            "loop_s": wall - (t1 - t0), "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
+            "definition": f"wall time of the full correlation function: {nt} steps of 0.005 fs x {n} trajectories, initial conditions "
+                          "included; 'converged' is quantified by the Monte-Carlo standard error below, not by a stopping rule",
+            "mc_standard_error_of_C_at_last_step": se,
+            "trajectories_for_1e-3_standard_error": int(np.ceil(n * (se / 1e-3) ** 2)),
+            "wall_to_1e-3_standard_error_s_extrapolated": (wall - (t1 - t0)) * (se / 1e-3) ** 2}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -440,7 +495,7 @@ def main():
         kern_ms = float(np.mean(step_ms))
         abytes = algorithmic_bytes_per_traj_step(dim) * n
         achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_source = profiled_traffic(n, dim)
+        traffic, traffic_source = profiled_traffic(n, dim, kern_ms)
         out = {
             "metric": "trajectory-steps/sec + wall-time to converged C(t), anharmonic-AS D=60",
             "value": n_total * K / wall, "unit": "trajectory-steps/s",
@@ -477,6 +532,10 @@ def main():
             if not args.no_cpu_baseline:          # rank 0 at N = 1 only
                 out["cpu_baseline"] = cpu_baseline(omega, chi, nac, q0, dt)
         print(json.dumps(out), flush=True)
+        broken = [k for k, v in out.get("configs", {}).items() if "error" in v]
+        if broken:                                # the line above is complete; a broken side configuration still fails the run
+            sys.stderr.write(f"bench.py: side configuration(s) failed: {', '.join(broken)}\n")
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

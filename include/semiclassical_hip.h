@@ -91,7 +91,9 @@ typedef struct sc_state {
     int32_t *flags;         /* [n + 2], zero-initialised scratch: flags[i] != 0 marks a trajectory whose determinant
                                the fast path hands to the fully pivoted elimination, flags[n] counts them for the
                                current step, flags[n + 1] is the cursor through which the fast kernel hands out
-                               trajectories to its workgroups (may be NULL: no fallback, static assignment) */
+                               trajectories to its workgroups.  May be NULL: the fixed-pivot-order register kernels
+                               (which rely on the fix-up) are then not used at all -- every trajectory takes the fully
+                               pivoted LDS kernel, correct but several times slower */
 } sc_state;
 
 /* constants of the HK prefactor, reference propagators.py:951-1004.
@@ -157,8 +159,8 @@ typedef struct sc_wm_consts {
     int64_t scratch_bytes;
     /* [n + 1] int32 scratch, or NULL.  The register-resident kernel eliminates in a fixed pivot order; a trajectory
      * whose pivot falls more than a factor 16 below what partial pivoting would have picked is marked flags[i] = 1
-     * (flags[n] counts them) and recomputed with full partial pivoting by the LDS kernel in the same call.  NULL: no
-     * such re-run (the fixed-order result is used as it is). */
+     * (flags[n] counts them) and recomputed with full partial pivoting by the LDS kernel in the same call.  NULL: the
+     * register kernel is not used, every trajectory takes the fully pivoted LDS kernel. */
     int32_t *flags;
     /* [n][3 D + 3] or NULL.  Position-dependent derivative couplings (potentials whose derivative_coupling_1st / _2nd
      * depend on r; the reference evaluates them at the initial and the current points of every trajectory,
@@ -216,8 +218,9 @@ int sc_state_to_reference(const sc_state *st, double *y, void *stream);
  * sgn = 1; st->mono is written ROW-MAJOR).
  *   ilz   [2d'][2D] row-major = block_diag(iLq, iLp) (:506-528), z0 [2D] = (q0, p0), prob0 = detLz/(2 pi)^D
  *   zi_t  [n][2D] out, probi [n] out, xi_out [n][2d'] out or NULL (the deviates themselves)
- * Deviates: Philox4x32-10 + Box-Muller; deviate j of the trajectory with GLOBAL index first + i depends only on
- * (seed, subsequence, first + i, j) -- not on n, the launch shape or the rank that draws it.  d' <= 256. */
+ * Deviates: Philox4x32-10 + Box-Muller, key = seed, counter = (trajectory index, pair index, subsequence): deviate j of the
+ * trajectory with GLOBAL index first + i depends only on (seed, subsequence, first + i, j) -- not on n, the launch shape or
+ * the rank that draws it -- and distinct (seed, subsequence) never share a stream.  d' <= 256, subsequence < 2^56. */
 int sc_sample_initial(const sc_state *st, const double *ilz, const double *z0, int32_t dprime, double prob0,
                       uint64_t seed, uint64_t subsequence, int64_t first, int32_t init_state, double *zi_t,
                       double *probi, double *xi_out, void *stream);

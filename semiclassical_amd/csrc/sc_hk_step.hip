@@ -258,6 +258,11 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     if (!dense && pot->kind != SC_POT_MORSE && pot->kind != SC_POT_HARMONIC_SEP && pot->kind != SC_POT_EPS_MORSE)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown potential kind %d", pot->kind);
     bool fast = !dense && hk->diag && st->work;
+    // The register kernels for D <= 12 and 16 < D <= 64 eliminate in a fixed (block-)pivot order and hand weak pivots to
+    // the fully pivoted fix-up launch THROUGH st->flags.  Without the flag array there is no fix-up, and a zero leading
+    // pivot would end as inf / NaN in c2: such callers get the fully pivoted LDS kernel for every trajectory instead.
+    // (13 <= D <= 16: hk_step_w16_kernel pivots over the whole row by itself.)
+    if (!st->flags && !(D > SC_SEP16_MAX_D && D <= 16)) fast = false;
     if (st->mono_layout != SC_MONO_ROWMAJOR && st->mono_layout != SC_MONO_TILED16)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step: unknown mono_layout %d", st->mono_layout);
     if (st->mono_layout == SC_MONO_TILED16 && D > 16 && !fast)
@@ -297,7 +302,7 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
     const int threads = step_threads(D), grid = sc_step_grid(st->n, D);
     hipStream_t s = (hipStream_t)stream;
     // constant Hessian, D <= 16 and the step matrix Phi(dt) at hand: the register kernel of sc_hk_step_lin.hip
-    if (dense && D <= 16 && (mode == 1 || (mode == 0 && pot->lin_prop && pot->lin_dt == dt))) {
+    if (dense && D <= 16 && st->flags && (mode == 1 || (mode == 0 && pot->lin_prop && pot->lin_dt == dt))) {
         if (st->flags && hipMemsetAsync(st->flags + st->n, 0, sizeof(int32_t), s) != hipSuccess)
             return sc_check_launch("sc_hk_step (flag counter)");
         const int rc = sc_launch_step_lin(a, grid, s);

@@ -4,9 +4,12 @@
 //
 // The reference draws xi with torch's generator on its compute device; the stream of deviates is therefore a property
 // of the torch build, not of the reference.  Here the deviates come from Philox4x32-10 (Salmon et al., SC'11: ten
-// rounds, multipliers 0xD2511F53 / 0xCD9E8D57, Weyl constants 0x9E3779B9 / 0xBB67AE85) keyed by (seed, subsequence):
-//     counter = (trajectory index lo, hi, pair index j/2, 0),  key = (seed ^ lo(subsequence * golden), hi-part)
-// one call gives 128 bits = two 53-bit uniforms = one Box-Muller pair (xi_j, xi_j+1).  A deviate depends only on
+// rounds, multipliers 0xD2511F53 / 0xCD9E8D57, Weyl constants 0x9E3779B9 / 0xBB67AE85):
+//     key     = (seed lo, seed hi)
+//     counter = (trajectory index lo, trajectory index hi, pair index | subsequence[32..55] << 8, subsequence[0..31])
+// Every (seed, subsequence, trajectory, pair) is a DISTINCT Philox input (pair index < 256, subsequence < 2^56): no two
+// (seed, subsequence) combinations can collide into one stream (round 3 folded the subsequence into the key by xor).
+// One call gives 128 bits = two 53-bit uniforms = one Box-Muller pair (xi_j, xi_j+1).  A deviate depends only on
 // (seed, subsequence, GLOBAL trajectory index, j): the ensemble is the same however the trajectories are split over
 // launches or ranks (rank r passes its first global index as `first`), and ranks that pass different subsequences
 // draw independent ensembles.
@@ -60,15 +63,15 @@ struct SampleArgs {
 __global__ __launch_bounds__(256) void sample_initial_kernel(SampleArgs A) {
     __shared__ double xis[4][SC_SAMPLE_MAX_E];
     const int D = A.st.dim, D2 = 2 * D, dp = A.dprime, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t kmix = A.seed ^ (A.subsequence * 0x9E3779B97F4A7C15ull);
-    const PhiloxKey key = {(uint32_t)kmix, (uint32_t)(kmix >> 32)};
+    const PhiloxKey key = {(uint32_t)A.seed, (uint32_t)(A.seed >> 32)};
+    const uint32_t sub_lo = (uint32_t)A.subsequence, sub_hi = (uint32_t)(A.subsequence >> 32) << 8;
     for (int64_t tr = (int64_t)blockIdx.x * 4 + wave; tr < A.st.n; tr += (int64_t)gridDim.x * 4) {
         const uint64_t g = (uint64_t)(A.first + tr);
         double half = 0.0;
         // pair p = (xi_p, xi_{p + d'}): the position and the momentum deviate of non-zero mode p
         for (int p = lane; p < dp; p += 64) {
             uint32_t r[4];
-            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p, 0u, key, r);
+            philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)p | sub_hi, sub_lo, key, r);
             const double u1 = uniform_open0(r[0], r[1]), u2 = uniform_open0(r[2], r[3]);
             const double rad = sqrt(-2.0 * log(u1));
             double sn, cs;
@@ -120,6 +123,9 @@ extern "C" int sc_sample_initial(const sc_state *st, const double *ilz, const do
     if (!st || !ilz || !z0 || !zi_t || !probi) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_sample_initial: null argument");
     if (st->n < 0 || st->dim < 1 || dprime < 1 || dprime > st->dim)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_sample_initial: n = %lld, D = %d, d' = %d", (long long)st->n, st->dim, dprime);
+    if (subsequence >> 56)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_sample_initial: subsequence %llu does not fit the counter (< 2^56)",
+                       (unsigned long long)subsequence);
     if (2 * dprime > SC_SAMPLE_MAX_E)
         return sc_fail(SC_ERR_UNSUPPORTED, "sc_sample_initial: d' = %d (at most %d non-zero modes are sampled on the device; "
                        "sample on the host and use set_initial_conditions)", dprime, SC_SAMPLE_MAX_E / 2);

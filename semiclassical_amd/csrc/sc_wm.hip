@@ -619,7 +619,9 @@ extern "C" int sc_wm_correlate(const sc_state *st, const sc_wm_consts *wc, const
         hipLaunchKernelGGL(wm_kernel<false>, dim3(nblocks), dim3(threads), bytes, s, a);
         return sc_check_launch("sc_wm_correlate");
     };
-    if (wm_has_small_kernel(D, dp) && !wc->nac_traj) {          // per-trajectory coupling vectors: the general kernel
+    // the register kernel eliminates in a fixed pivot order and needs wc->flags to hand weak pivots to the pivoted re-run:
+    // without flags (or with per-trajectory coupling vectors) every trajectory takes the fully pivoted general kernel
+    if (wm_has_small_kernel(D, dp) && !wc->nac_traj && wc->flags) {
         if (!wc->scratch || wc->scratch_bytes < sc_wm_scratch_bytes(st->n, D, dp))
             return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_wm_correlate: D=%d d'=%d needs a scratch buffer of %lld B (sc_wm_scratch_bytes), "
                            "got %lld", D, dp, (long long)sc_wm_scratch_bytes(st->n, D, dp), (long long)wc->scratch_bytes);

@@ -121,13 +121,15 @@ class HermanKlukPropagator(object):
         prob0 = detLz / (2 * np.pi) ** d
         if seed is not None:
             assert generator is None, "either a host generator or a device seed"
+            if not 0 <= int(subsequence) < 2 ** 56:
+                raise ValueError(f"subsequence {subsequence} outside [0, 2^56)")
             dev = self.device
             self._begin_state(q0, p0, Gamma_0, U, iGi0, int(ntraj), ntraj_total)
             self._zi_t = torch.empty((ntraj, 2 * d), dtype=F64, device=dev)
             self.probi = torch.empty(ntraj, dtype=F64, device=dev)
             ilz_d, z0_d = iLz.contiguous().to(dev), z0.to(dev)
             check(lib.sc_sample_initial(self._state, ptr(ilz_d), ptr(z0_d), dprime, float(prob0), int(seed) & (2 ** 64 - 1),
-                                        int(subsequence) & (2 ** 64 - 1), int(first_index), 1, ptr(self._zi_t),
+                                        int(subsequence), int(first_index), 1, ptr(self._zi_t),
                                         ptr(self.probi), None, self._stream()))
             self.zi = self._zi_t.t()                   # the reference's (2D, n) attribute, as a view
             self._finish_state((ilz_d, z0_d))
@@ -434,6 +436,7 @@ class HermanKlukPropagator(object):
 
     def synchronize(self):
         torch.cuda.current_stream(self.device).synchronize()
+        self._run_scratch = None              # partial sums of the last whole-loop run(): consumed by now
         self._check_energy_guard()
 
     def mean_energy(self):
@@ -563,7 +566,9 @@ class HermanKlukPropagator(object):
 
         Returns ``(autocorrelation[nt], ic_correlation[nt])`` as complex NumPy arrays.  With ``slots`` (a
         device tensor (nt, 5)) the raw sums are left on the device for a later flush (see distributed.py)
-        and ``None`` is returned.
+        and ``None`` is returned.  Columns 0..3 of row k are Re C, Im C, Re k, Im k of the state before step k.
+        Column 4 belongs to the engine: the whole-loop kernel (``sc_hk_run``) leaves the mean <T+V> of step k there,
+        the step-at-a-time paths do not touch it -- do not keep data of your own in it across ``run()``.
 
         ``use_graph``: for small batches the loop is bound by the ~6 kernel launches per step, not by the kernels.
         The first iteration then runs as usual and the launch sequence of the second one is captured in a HIP graph
@@ -610,9 +615,10 @@ class HermanKlukPropagator(object):
         self._sync_dense_mono(leave_diagonal=True)
         self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
         nslots = lib.sc_hk_run_slots(self.ntraj, self.dim)
-        # per-step partial sums of every wavefront: 40 nslots bytes per step; long runs go in launches of <= 4096 steps
-        # (<= 0.7 GB of partials, reused: the launches are ordered on the stream), the state stays on the device in between
-        chunk = min(nt, 4096)
+        # per-step partial sums of every wavefront: 40 nslots bytes per step; long runs go in launches of <= 512 steps
+        # (<= 84 MB of partials at 4096 slots, reused: the launches are ordered on the stream), the state stays on the device
+        # in between and is read / written once per launch (<= 1 KB per trajectory at D <= 12: negligible against 512 steps)
+        chunk = min(nt, 512)
         partials = torch.empty((chunk, nslots, 5), dtype=F64, device=self.device)
         nac = self._nac
         for k0 in range(0, nt, chunk):

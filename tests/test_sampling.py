@@ -43,7 +43,7 @@ def test_device_deviates_and_formulas(D, deficient):
     from semiclassical_amd import hostmath, propagators as PR
     from semiclassical_amd._lib import lib, check, ptr
     G, q0, p0 = _setup(D, deficient)
-    n, seed, sub, first = 777, 2024, 3, 10 ** 10 + 5
+    n, seed, sub, first = 777, 2024, 3 + (5 << 32), 10 ** 10 + 5        # subsequence with bits above 2^32
     prop = PR.HermanKlukPropagator(G, G, device="cuda")
     prop.initial_conditions(q0, p0, G, ntraj=n, seed=seed, subsequence=sub, first_index=first)
     U, iGi0, iLz, detLz, dp = hostmath.sampling_matrices(G, G)
@@ -86,6 +86,14 @@ def test_device_ensemble_is_independent_of_the_split_and_of_the_launch():
     other = PR.HermanKlukPropagator(G, G, device="cuda")
     other.initial_conditions(q0, p0, G, ntraj=1000, seed=9, subsequence=1)
     assert float((other._zi_t - whole._zi_t).abs().min()) > 0.0       # another subsequence: another ensemble
+    # (seed, subsequence) pairs that collided when the subsequence was xor-ed into the key (round 3): distinct streams now
+    golden = 0x9E3779B97F4A7C15
+    a, b = PR.HermanKlukPropagator(G, G, device="cuda"), PR.HermanKlukPropagator(G, G, device="cuda")
+    a.initial_conditions(q0, p0, G, ntraj=64, seed=9, subsequence=1)
+    b.initial_conditions(q0, p0, G, ntraj=64, seed=9 ^ golden, subsequence=0)
+    assert float((a._zi_t - b._zi_t).abs().min()) > 0.0
+    with pytest.raises(ValueError, match="subsequence"):
+        a.initial_conditions(q0, p0, G, ntraj=4, seed=1, subsequence=2 ** 56)
 
 
 @pytest.mark.gpu
