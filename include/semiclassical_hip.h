@@ -100,9 +100,12 @@ typedef struct sc_state {
  * diag != 0: Gamma_i, Gamma_t diagonal and of full rank; st = sqrt(diag Gamma_t),
  *            si = sqrt(diag Gamma_i).
  * diag == 0: L1 = U^T Gt^{1/2}, L2 = U^T Gt^{-1/2} (d' x D complex),
- *            R1 = Gi^{-1/2} U,  R2 = Gi^{1/2} U   (D x d' complex). */
+ *            R1 = Gi^{-1/2} U,  R2 = Gi^{1/2} U   (D x d' complex).
+ *            real_lr != 0: the caller asserts that the imaginary parts of all four are zero (they are products of real
+ *            matrices for positive semi-definite widths; the reference's complex128 copies carry rounding dust at most):
+ *            the register kernels then run the sandwiches in real arithmetic.  0 is always correct. */
 typedef struct sc_hk_consts {
-    int32_t dim, dprime, diag, _pad;
+    int32_t dim, dprime, diag, real_lr;
     const double *st, *si;
     const double *L1, *L2, *R1, *R2;
 } sc_hk_consts;
@@ -262,9 +265,11 @@ int sc_reduce_slot(const double *corr_partials, int32_t n_corr, const double *en
 int sc_reduce_slot_at(const double *corr_partials, int32_t n_corr, double *slots, int64_t *cursor, void *stream);
 
 /* The WHOLE caller loop (cli.py:401-436: nsteps times "autocorrelation, ic_correlation, step") in one launch, for
- * separable potentials (SC_POT_MORSE / HARMONIC_SEP / EPS_MORSE) with diagonal width matrices and D <= 12: a trajectory is
- * loaded once into registers, runs all steps there and is written back once (sc_hk_run_supported says whether the
- * combination qualifies; everything else takes sc_hk_correlate / sc_hk_step step by step).  Arguments as for
+ *   - separable potentials (SC_POT_MORSE / HARMONIC_SEP / EPS_MORSE) with diagonal width matrices and D <= 12,
+ *   - a constant dense Hessian (SC_POT_HARMONIC_DENSE with its step matrix lin_prop built for this dt), any width matrices
+ *     (hk->real_lr for dense ones), at the small molecular shapes D <= 12 the library instantiates (methylium: D = 12, d' = 6):
+ * a trajectory is loaded once into registers, runs all steps there and is written back once (sc_hk_run_supported says
+ * whether the combination qualifies; everything else takes sc_hk_correlate / sc_hk_step step by step).  Arguments as for
  * sc_hk_correlate and sc_hk_step.  partials: scratch of 5 * sc_hk_run_slots(n, D) * nsteps doubles;
  * slots_out [nsteps][5]: row k = Re C, Im C, Re k, Im k summed over the trajectories for the state BEFORE step k (what
  * sc_hk_correlate + sc_reduce_slot give) and the mean <T+V> at the k4 stage of step k; elog: the energy-guard log of

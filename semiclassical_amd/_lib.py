@@ -26,7 +26,7 @@ class sc_state(C.Structure):
 
 
 class sc_hk_consts(C.Structure):
-    _fields_ = [("dim", C.c_int32), ("dprime", C.c_int32), ("diag", C.c_int32), ("_pad", C.c_int32),
+    _fields_ = [("dim", C.c_int32), ("dprime", C.c_int32), ("diag", C.c_int32), ("real_lr", C.c_int32),
                 ("st", c_double_p), ("si", c_double_p),
                 ("L1", c_double_p), ("L2", c_double_p), ("R1", c_double_p), ("R2", c_double_p)]
 

@@ -18,22 +18,10 @@
 //                                                         separable potential produces from M(0) = 1) repeats the
 //                                                         elimination with the pivot searched among the lanes
 //                                                         (propagators.py:969-1052)
-#include "sc_common.h"
+#include "sc_hk_run.h"
 #include "sc_row16.h"
 
 namespace {
-
-struct RunArgs {
-    StepArgs step;              // potential, state, prefactor constants, dt
-    sc_overlap_consts oc;       // <q_t, p_t, Gamma_t | q0, p0, Gamma_0>: diagonal
-    sc_nac_consts nc;
-    int has_nac;
-    const double *vi, *probi, *nacq;
-    double mc_norm;
-    int nsteps;
-    double *partials;           // [nsteps][slots][5]: Re C, Im C, Re k, Im k, sum of (T+V) at the k4 stage; zeroed by the caller
-    int slots;                  // 4 * gridDim.x
-};
 
 // value of `v` in lane 0 of each 16-lane row, summed over the four rows of the wavefront (result in every lane)
 __device__ __forceinline__ double sum_row_heads(double v, bool head) { return wave_sum(head ? v : 0.0); }
@@ -227,10 +215,20 @@ extern "C" int sc_hk_run_slots(int64_t n, int32_t dim) {
     return 4 * (int)(groups < 1024 ? (groups > 0 ? groups : 1) : 1024);
 }
 
+// constant dense Hessian with its step matrix, D <= 16 at the shapes sc_hk_run_lin.hip instantiates (real L, R)
+static bool run_lin_shape(const sc_potential *pot, const sc_hk_consts *hk) {
+    if (pot->kind != SC_POT_HARMONIC_DENSE || !pot->lin_prop || pot->dim > 16 || hk->dim != pot->dim) return false;
+    RunArgs probe{};
+    probe.step.st.dim = pot->dim;
+    probe.step.hk = *hk;
+    return sc_launch_run_lin(probe, 0, nullptr, 0) == 1;
+}
+
 extern "C" int sc_hk_run_supported(const sc_potential *pot, const sc_hk_consts *hk, const sc_overlap_consts *ovl) {
     if (!pot || !hk || !ovl) return 0;
     const bool sep = pot->kind == SC_POT_MORSE || pot->kind == SC_POT_HARMONIC_SEP || pot->kind == SC_POT_EPS_MORSE;
-    return sep && hk->diag && ovl->diag && pot->dim <= SC_SEP16_MAX_D ? 1 : 0;
+    if (sep && hk->diag && ovl->diag && pot->dim <= SC_SEP16_MAX_D) return 1;
+    return run_lin_shape(pot, hk) ? 1 : 0;
 }
 
 extern "C" int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
@@ -240,8 +238,12 @@ extern "C" int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_h
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: null argument");
     if (nc && !nacq) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: nac constants without nacq");
     if (!sc_hk_run_supported(pot, hk, ovl_t0))
-        return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_run: needs a separable potential, diagonal width matrices and D <= %d "
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_run: needs a separable potential with diagonal width matrices and D <= %d, or a "
+                       "constant dense Hessian with its step matrix (sc_potential.lin_prop) at an instantiated shape D <= 16 "
                        "(use the step-by-step entry points)", SC_SEP16_MAX_D);
+    const bool lin = pot->kind == SC_POT_HARMONIC_DENSE;
+    if (lin && pot->lin_dt != dt)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: the step matrix was built for dt = %g, the call asks for %g", pot->lin_dt, dt);
     if (pot->dim != st->dim || hk->dim != st->dim || ovl_t0->dim != st->dim)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: dimension mismatch");
     if (int rq = sc_require_rowmajor(st, "sc_hk_run")) return rq;
@@ -256,6 +258,14 @@ extern "C" int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_h
     if (hipMemsetAsync(partials, 0, sizeof(double) * 5 * (size_t)a.slots * (size_t)nsteps, s) != hipSuccess)
         return sc_check_launch("sc_hk_run (partials)");
     const int grid = a.slots / 4, D = st->dim;
+    if (lin) {
+        int rc = sc_launch_run_lin(a, grid, s, 1);
+        if (rc < 0) return rc;
+        if (rc == 0) return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_run: shape D=%d d'=%d not instantiated", D, hk->dprime);
+        hipLaunchKernelGGL(hk_run_reduce_kernel, dim3(nsteps), dim3(256), 0, s, partials, a.slots, (double)st->n, slots_out);
+        hipLaunchKernelGGL(hk_run_guard_kernel, dim3(1), dim3(64), 0, s, slots_out, nsteps, elog);
+        return sc_check_launch("sc_hk_run (reduction)");
+    }
 #define SC_RUN_K(DP_, KIND_) hipLaunchKernelGGL((hk_run_sep16_kernel<DP_, KIND_>), dim3(grid), dim3(256), 0, s, a)
 #define SC_RUN(DP_)                                                                     \
     do {                                                                                \

@@ -31,8 +31,6 @@
 
 namespace {
 
-typedef double lin_d2v __attribute__((ext_vector_type(2)));
-
 // Row prefetch through LDS (even D: a 16-byte unit never straddles two matrix rows).  The four trajectories of a wavefront
 // are contiguous in memory; per HALF of the product ([Mqq, Mpq], then [Mqp, Mpp]) they are 4 D^2 16-byte units, which the
 // wavefront requests with fully coalesced LDS-DMA loads (global_load_lds_dwordx4, 1 KB per instruction, no registers)
@@ -49,30 +47,6 @@ struct LinDma {
     static constexpr int zero_units = (DD + D + 1) / 2;       // rows of zeros for the lanes r >= D of a 16-lane row
     static constexpr int units = on ? 4 * wave_units + zero_units : 1;
 };
-
-// row r of two blocks (DD doubles apart) of the wavefront's buffer -> registers; the reads are inline assembly so that
-// the compiler does not put a vmcnt(0) (it cannot tell these reads from the LDS-DMA requests in flight) in front of them
-template <int D, int I>
-__device__ __forceinline__ void lin_lds_row_reads(unsigned addr, lin_d2v (&v)[D]) {
-    if constexpr (I < D / 2) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[I]) : "v"(addr), "n"(16 * I));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[D / 2 + I]) : "v"(addr), "n"(8 * D * D + 16 * I));
-        lin_lds_row_reads<D, I + 1>(addr, v);
-    }
-}
-template <int D>
-__device__ __forceinline__ void lin_lds_rows(unsigned addr, double (&Tq)[D], double (&Tp)[D]) {
-    lin_d2v v[D];
-    lin_lds_row_reads<D, 0>(addr, v);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < D; ++i) asm volatile("" : "+v"(v[i]));        // consumers are ordered behind the wait
-#pragma unroll
-    for (int i = 0; i < D / 2; ++i) {
-        Tq[2 * i] = v[i].x; Tq[2 * i + 1] = v[i].y;
-        Tp[2 * i] = v[D / 2 + i].x; Tp[2 * i + 1] = v[D / 2 + i].y;
-    }
-}
 
 // complex constant from LDS, read as two doubles
 __device__ __forceinline__ cplx lds_cplx(const cplx *p) { const double *d = (const double *)p; return c_make(d[0], d[1]); }
@@ -113,10 +87,13 @@ struct LinLayout {
     // meet on.  Unpadded, Phi's rows (4 D doubles = 96 dwords at D = 12) put all lanes on one bank: a 12-way conflict on
     // every read of the product loop, 87 % of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT).  One double (one complex
     // number) more per row spreads the lanes over the banks.
+    // L1, L2, R1, R2 are REAL here (round 4): they are products of U and real symmetric square roots of the positive
+    // semi-definite width matrices; the reference carries them as complex128 with imaginary parts that are zero or rounding
+    // dust (1e-24 for methylium).  sc_hk_consts.real_lr says so; widths with genuinely complex roots take the LDS kernel.
     static constexpr int PH = D + 1, PP = 4 * D + 1, PL = D + 1, PR = DP + 1;
     static constexpr int n_real = 16 * PH + 16 * PP + 8 * 16;
-    static constexpr int n_cplx = DIAG ? 0 : 2 * 16 * PL + 2 * 16 * PR;
-    static constexpr size_t bytes = (size_t)n_real * 8 + (size_t)n_cplx * 16 + 16 * 8;
+    static constexpr int n_lr = DIAG ? 0 : 2 * 16 * PL + 2 * 16 * PR;
+    static constexpr size_t bytes = (size_t)n_real * 8 + (size_t)n_lr * 8 + 16 * 8;
 };
 
 // Waves per SIMD: two for every shape (256 registers per lane).  The loop of the prefetching shapes must not spill: a scratch
@@ -139,23 +116,23 @@ __global__ __launch_bounds__(256, lin_occ<D>()) void hk_step_lin_kernel(StepArgs
     double *sH = ls;    ls += 16 * PH;
     double *sPhi = ls;  ls += 16 * PP;             // row a: Phi_qq[a][:], Phi_qp[a][:], Phi_pq[a][:], Phi_pp[a][:]
     double *svec = ls;  ls += 8 * 16;              // x0, g0, 1/m, st, 1/st
-    cplx *sL1 = (cplx *)ls, *sL2 = sL1 + 16 * PL;  // rows i < d' of L1, L2 (dense widths)
-    cplx *sR1 = sL2 + 16 * PL, *sR2 = sR1 + 16 * PR; // rows b < D of R1, R2
-    double *red = (double *)(sL1 + L::n_cplx);
+    double *sL1 = ls, *sL2 = sL1 + 16 * PL;        // rows i < d' of Re L1, Re L2 (dense widths)
+    double *sR1 = sL2 + 16 * PL, *sR2 = sR1 + 16 * PR; // rows b < D of Re R1, Re R2
+    double *red = sL1 + L::n_lr;
 
     for (int e = tid; e < 16 * D; e += 256) {
         const int i = e / D, b = e - i * D;
         sH[i * PH + b] = i < D ? A.pot.par2[i * D + b] : 0.0;
         if (!DIAG) {
-            sL1[i * PL + b] = i < DP ? ((const cplx *)A.hk.L1)[i * D + b] : c_make(0.0, 0.0);
-            sL2[i * PL + b] = i < DP ? ((const cplx *)A.hk.L2)[i * D + b] : c_make(0.0, 0.0);
+            sL1[i * PL + b] = i < DP ? A.hk.L1[2 * (i * D + b)] : 0.0;          // real parts of the interleaved complex arrays
+            sL2[i * PL + b] = i < DP ? A.hk.L2[2 * (i * D + b)] : 0.0;
         }
     }
     if (!DIAG) {
         for (int e = tid; e < 16 * DP; e += 256) {
             const int i = e / DP, j = e - i * DP;
-            sR1[i * PR + j] = i < D ? ((const cplx *)A.hk.R1)[i * DP + j] : c_make(0.0, 0.0);
-            sR2[i * PR + j] = i < D ? ((const cplx *)A.hk.R2)[i * DP + j] : c_make(0.0, 0.0);
+            sR1[i * PR + j] = i < D ? A.hk.R1[2 * (i * DP + j)] : 0.0;
+            sR2[i * PR + j] = i < D ? A.hk.R2[2 * (i * DP + j)] : 0.0;
         }
     }
     for (int e = tid; e < 16 * 4 * D; e += 256) {
@@ -277,7 +254,7 @@ __global__ __launch_bounds__(256, lin_occ<D>()) void hk_step_lin_kernel(StepArgs
         //                  mat' = 1/2 (L1 X1 + L2 X2): rows of X1, X2 from lane a, L1[i][a], L2[i][a] from LDS        (:969-994)
         cplx mat[N];
         constexpr int NS = DIAG ? 1 : DP;
-        cplx s1[NS], s2[NS], t1[NS], t2[NS];       // Mqq R1, Mqp R2, Mpp R2, Mpq R1
+        double s1[NS], s2[NS], t1[NS], t2[NS];     // Mqq R1, Mqp R2, Mpp R2, Mpq R1 (real: R1, R2 are)
         auto accum_half = [&](auto hc, const double (&Xhq)[D], const double (&Xhp)[D]) {
             constexpr int h = decltype(hc)::value;
             if constexpr (DIAG) {
@@ -290,21 +267,18 @@ __global__ __launch_bounds__(256, lin_occ<D>()) void hk_step_lin_kernel(StepArgs
                     }
                 }
             } else {
-                cplx rr[DP];
-                cplx (&uq)[NS] = h ? s2 : s1, (&up)[NS] = h ? t1 : t2;
+                double rr[DP];
+                double (&uq)[NS] = h ? s2 : s1, (&up)[NS] = h ? t1 : t2;
 #pragma unroll
                 for (int j = 0; j < DP; ++j) {
-                    rr[j] = lds_cplx((h ? sR2 : sR1) + r * PR + j + lofs);
-                    uq[j] = c_make(0.0, 0.0); up[j] = c_make(0.0, 0.0);
+                    rr[j] = ((h ? sR2 : sR1) + lofs)[r * PR + j];
+                    uq[j] = 0.0; up[j] = 0.0;
                 }
                 dpp_guard(rr);
                 sfor<0, D>([&](auto bcn) {
                     constexpr int b = decltype(bcn)::value;
 #pragma unroll
-                    for (int j = 0; j < DP; ++j) {
-                        fmac_bc<b>(uq[j].x, rr[j].x, Xhq[b]); fmac_bc<b>(uq[j].y, rr[j].y, Xhq[b]);
-                        fmac_bc<b>(up[j].x, rr[j].x, Xhp[b]); fmac_bc<b>(up[j].y, rr[j].y, Xhp[b]);
-                    }
+                    for (int j = 0; j < DP; ++j) { fmac_bc<b>(uq[j], rr[j], Xhq[b]); fmac_bc<b>(up[j], rr[j], Xhp[b]); }
                 });
             }
         };
@@ -444,19 +418,19 @@ __global__ __launch_bounds__(256, lin_occ<D>()) void hk_step_lin_kernel(StepArgs
             cplx X1[DP], X2[DP];
 #pragma unroll
             for (int j = 0; j < DP; ++j) {
-                X1[j] = c_add(s1[j], c_mul(c_make(0.0, -SC_HBAR), s2[j]));
-                X2[j] = c_add(t1[j], c_mul(c_make(0.0, 1.0 / SC_HBAR), t2[j]));
+                X1[j] = c_make(s1[j], -SC_HBAR * s2[j]);                 // Mqq R1 - i hbar Mqp R2
+                X2[j] = c_make(t1[j], (1.0 / SC_HBAR) * t2[j]);          // Mpp R2 + i/hbar Mpq R1
             }
 #pragma unroll
             for (int j = 0; j < DP; ++j) mat[j] = c_make(0.0, 0.0);
             dpp_guard(X1, X2);
             sfor<0, D>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
-                const cplx l1 = lds_cplx(sL1 + r * PL + a + lofs), l2 = lds_cplx(sL2 + r * PL + a + lofs);
+                const double l1 = (sL1 + lofs)[r * PL + a], l2 = (sL2 + lofs)[r * PL + a];
 #pragma unroll
-                for (int j = 0; j < DP; ++j) cfma_bc<a>(mat[j], X1[j], l1);
+                for (int j = 0; j < DP; ++j) { fmac_bc<a>(mat[j].x, X1[j].x, l1); fmac_bc<a>(mat[j].y, X1[j].y, l1); }
 #pragma unroll
-                for (int j = 0; j < DP; ++j) cfma_bc<a>(mat[j], X2[j], l2);
+                for (int j = 0; j < DP; ++j) { fmac_bc<a>(mat[j].x, X2[j].x, l2); fmac_bc<a>(mat[j].y, X2[j].y, l2); }
             });
 #pragma unroll
             for (int j = 0; j < DP; ++j) mat[j] = c_scale(mat[j], 0.5);
@@ -518,6 +492,7 @@ int launch(const StepArgs &a, int grid, hipStream_t s) {
 int sc_launch_step_lin(const StepArgs &a, int grid, hipStream_t s) {
     const int D = a.st.dim, dp = a.hk.dprime;
     const bool diag = a.hk.diag != 0;
+    if (!diag && !a.hk.real_lr) return 0;       // genuinely complex L, R (indefinite rounding in the widths): the LDS kernel
 #define SC_LIN_CASE(D_, DP_, DIAG_) if (D == D_ && dp == DP_ && diag == DIAG_) return launch<D_, DP_, DIAG_>(a, grid, s);
     SC_LIN_CASE(12, 6, false) SC_LIN_CASE(12, 12, true) SC_LIN_CASE(9, 3, false) SC_LIN_CASE(9, 9, true)
     SC_LIN_CASE(6, 6, true) SC_LIN_CASE(6, 6, false) SC_LIN_CASE(3, 3, true)

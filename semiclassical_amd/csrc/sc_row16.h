@@ -150,6 +150,34 @@ __device__ __forceinline__ void cfnma_inplace_range(cplx (&v)[N], const cplx &w)
         cfnma_inplace_range<K, I0 + 3, I1>(v, w);
     }
 }
+// ---- rows of a trajectory's monodromy blocks staged in LDS by LDS-DMA (global_load_lds_dwordx4), read back one row per lane ----
+typedef double lin_d2v __attribute__((ext_vector_type(2)));
+
+// row r of two blocks (DD doubles apart) of the wavefront's buffer -> registers; the reads are inline assembly so that
+// the compiler does not put a vmcnt(0) (it cannot tell these reads from the LDS-DMA requests in flight) in front of them
+template <int D, int I>
+__device__ __forceinline__ void lin_lds_row_reads(unsigned addr, lin_d2v (&v)[D]) {
+    if constexpr (I < D / 2) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[I]) : "v"(addr), "n"(16 * I));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(v[D / 2 + I]) : "v"(addr), "n"(8 * D * D + 16 * I));
+        lin_lds_row_reads<D, I + 1>(addr, v);
+    }
+}
+template <int D>
+__device__ __forceinline__ void lin_lds_rows(unsigned addr, double (&Tq)[D], double (&Tp)[D]) {
+    lin_d2v v[D];
+    lin_lds_row_reads<D, 0>(addr, v);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < D; ++i) asm volatile("" : "+v"(v[i]));        // consumers are ordered behind the wait
+#pragma unroll
+    for (int i = 0; i < D / 2; ++i) {
+        Tq[2 * i] = v[i].x; Tq[2 * i + 1] = v[i].y;
+        Tp[2 * i] = v[D / 2 + i].x; Tp[2 * i + 1] = v[D / 2 + i].y;
+    }
+}
+
+
 // value of lane K of the row (32-bit)
 template <int K>
 __device__ __forceinline__ int bc_i32(int v) {

@@ -235,7 +235,11 @@ class HermanKlukPropagator(object):
         if self._pre.diag:
             self._hk = sc_hk_consts(dim=self.dim, dprime=self.dim, diag=1, st=ptr(b[0]), si=ptr(b[1]))
         else:
-            self._hk = sc_hk_consts(dim=self.dim, dprime=self._pre.dprime, diag=0,
+            # imaginary parts of U^T Gt^(+-1/2), Gi^(-+1/2) U: zero for positive semi-definite widths up to rounding dust
+            # (1e-24 for methylium); "real" = below one ulp of the largest entry, so dropping them changes no bit
+            real = all(float(m.imag.abs().max()) <= 1e-17 * float(m.real.abs().max()) for m in
+                       (self._pre.L1, self._pre.L2, self._pre.R1, self._pre.R2))
+            self._hk = sc_hk_consts(dim=self.dim, dprime=self._pre.dprime, diag=0, real_lr=int(real),
                                     L1=ptr(b[0]), L2=ptr(b[1]), R1=ptr(b[2]), R2=ptr(b[3]))
         self._ovl_i0, self._ovl_i0_bufs = self._overlap_consts(self._Gi, self._G0h)
         self._ovl_t0, self._ovl_t0_bufs = self._overlap_consts(self._Gt, self._G0h)

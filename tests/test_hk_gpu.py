@@ -664,3 +664,75 @@ def test_whole_loop_kernel_with_dense_blocks_and_ragged_batch():
     assert cases.rel_err(ca, cb) < 1e-12 and cases.rel_err(ka, kb) < 1e-12
     assert torch.equal(a._sgn, b._sgn)
     assert cases.rel_err(cnp(a._c2), cnp(b._c2)) < 1e-11 and cases.rel_err(cnp(a.y), cnp(b.y)) < 1e-13
+
+
+def test_whole_loop_kernel_for_the_constant_hessian_matches_stepwise_path_and_golden():
+    """sc_hk_run for a constant dense Hessian (round 4; hk_run_lin_kernel: methylium, D = 12, rank-6 Cartesian widths): the
+    reference's golden C(t), k_ic(t) through run() at 1e-9, the step-at-a-time path of the same engine at 1e-13 with bit-equal
+    branch signs, the same state, determinants and energy means -- and the loop continues step by step afterwards."""
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load("hk_methylium")
+    nt, dt, E0 = int(g["nt"]), float(g["dt"]), float(g["E0"])
+    fused, stepwise = engine_propagator(g), engine_propagator(g)
+    stepwise._whole_loop_ok = False
+    pot = engine_potential(g)
+    assert fused._whole_loop_applies(fused._potential_descriptor(pot, dt))
+    c1, k1 = fused.run(pot, dt, nt, E0)
+    c2, k2 = stepwise.run(pot, dt, nt, E0)
+    assert cases.rel_err(c1, c2) < 1e-13 and cases.rel_err(k1, k2) < 1e-13, (cases.rel_err(c1, c2), cases.rel_err(k1, k2))
+    assert cases.rel_err(c1, g["cauto"]) < 1e-9 and cases.rel_err(k1, g["kic"]) < 1e-9
+    assert torch.equal(fused._sgn, stepwise._sgn)
+    assert cases.rel_err(cnp(fused.y), cnp(stepwise.y)) < 1e-13
+    assert cases.rel_err(cnp(fused._c2), cnp(stepwise._c2)) < 1e-12
+    assert abs(fused.t - stepwise.t) == 0.0 and fused._nsteps == stepwise._nsteps
+    assert cases.rel_err(cnp(fused._elog), cnp(stepwise._elog)) < 1e-12
+    fused.step(pot, dt); stepwise.step(pot, dt)
+    assert abs(fused.autocorrelation(E0) - stepwise.autocorrelation(E0)) < 1e-13 * abs(stepwise.autocorrelation(E0))
+
+
+@pytest.mark.parametrize("D,zero_modes,diag", [(12, 6, False), (12, 0, True), (9, 6, False), (6, 0, True), (6, 0, False), (3, 0, True),
+                                               (6, 5, False), (9, 5, False), (12, 5, False), (9, 0, True)])
+def test_whole_loop_constant_hessian_shapes_dense_blocks_and_ragged_batch(D, zero_modes, diag):
+    """every instantiated shape of hk_run_lin_kernel (diagonal widths, rotated full-rank and rank-deficient widths) on a ragged
+    batch with random dense monodromy blocks -- part of the fixed-order eliminations meet weak pivots and are repeated with
+    the pivot searched among the lanes -- against the step-at-a-time path (whose weak pivots go to the fix-up launch)"""
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    rng = np.random.default_rng(100 + 7 * D + zero_modes)
+    n, nt, dt = 203, 5, 2.0
+    w = np.sort(rng.uniform(500, 3000, D)) / 219474.63
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    masses = rng.uniform(0.8, 1.5, D) * 1822.0
+    hess = (Q * (w ** 2 * 1822.0)) @ Q.T
+    hess = 0.5 * (hess + hess.T)
+    if diag:
+        G = torch.diag(torch.from_numpy(w * 1822.0))
+    else:
+        ww = w * 1822.0 * rng.uniform(0.7, 1.4, D)
+        ww[:zero_modes] = 0.0
+        Qg, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        G = torch.from_numpy((Qg * ww) @ Qg.T)
+        G = 0.5 * (G + G.T)
+    pos0 = rng.normal(0, 0.05, D)
+    pot_args = (pos0, -0.3, rng.normal(0, 1e-3, D), hess, masses, rng.normal(0, 1e-3, D))
+    q0 = torch.from_numpy(pos0 + rng.normal(0, 0.02, D))
+    E0 = 0.01
+    gen = torch.Generator().manual_seed(2)
+    blocks = [torch.eye(D).unsqueeze(2) * (k in (0, 3)) + 0.4 * torch.randn(D, D, n, generator=gen) for k in range(4)]
+    props = []
+    for whole in (True, False):
+        pot = P.MolecularHarmonicPotential.from_arrays(*pot_args, origin=-0.3)
+        prop = PR.HermanKlukPropagator(G, G, device="cuda")
+        prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(5))
+        y = prop.y
+        for k, blk in enumerate(blocks):
+            y[2 * D + k * D * D: 2 * D + (k + 1) * D * D] = blk.reshape(D * D, n).cuda()
+        prop.y = y
+        prop._whole_loop_ok = whole
+        if whole:
+            assert prop._whole_loop_applies(prop._potential_descriptor(pot, dt)), "shape not taken by the whole-loop kernel"
+        props.append((prop, prop.run(pot, dt, nt, E0)))
+    (a, (ca, ka)), (b, (cb, kb)) = props
+    assert np.isfinite(ca).all() and cases.rel_err(ca, cb) < 1e-12 and cases.rel_err(ka, kb) < 1e-12
+    assert torch.equal(a._sgn, b._sgn)
+    assert cases.rel_err(cnp(a._c2), cnp(b._c2)) < 1e-10 and cases.rel_err(cnp(a.y), cnp(b.y)) < 1e-13
