@@ -30,8 +30,11 @@ struct RunLinLayout {
     static constexpr size_t bytes = (size_t)n_doubles * 8;
 };
 
+#ifndef SC_RUNLIN_OCC
+#define SC_RUNLIN_OCC 2
+#endif
 template <int D, int DP, bool DIAG>
-__global__ __launch_bounds__(256, 2) void hk_run_lin_kernel(RunArgs R) {
+__global__ __launch_bounds__(256, SC_RUNLIN_OCC) void hk_run_lin_kernel(RunArgs R) {
     typedef RunLinLayout<D, DP, DIAG> L;
     constexpr int W = 2 * D, DD = D * D, N = DIAG ? D : DP;
     constexpr int PH = L::PH, PP = L::PP, PL = L::PL, PR = L::PR, PD = L::PD;
@@ -135,14 +138,15 @@ __global__ __launch_bounds__(256, 2) void hk_run_lin_kernel(RunArgs R) {
                 double dq = qk - q, dpp = pk - p;
                 if (r >= D) { dq = 0.0; dpp = 0.0; }
                 double ya = 0.0, yb = 0.0, yc = 0.0;
-                double ra[D], rb[D], rc[D];
-#pragma unroll
-                for (int b = 0; b < D; ++b) { ra[b] = cA[b]; rb[b] = cB[b]; rc[b] = cC[b]; }
                 dpp_guard(dq, dpp);
-                sfor<0, D>([&](auto bcn) {
-                    constexpr int b = decltype(bcn)::value;
-                    fmac_bc<b>(ya, dq, ra[b]); fmac_bc<b>(yb, dpp, rb[b]); fmac_bc<b>(yc, dpp, rc[b]);
-                });
+                // one matrix after the other (a row of constants is 2 D registers, and 4 D^2 / 16 * 2 are taken by the trajectory)
+                auto times_row = [&](double &y, const double &x, const double *row) {
+                    double rw[D];
+#pragma unroll
+                    for (int b = 0; b < D; ++b) rw[b] = row[b];
+                    sfor<0, D>([&](auto bcn) { fmac_bc<decltype(bcn)::value>(y, x, rw[decltype(bcn)::value]); });
+                };
+                times_row(ya, dq, cA); times_row(yb, dpp, cB); times_row(yc, dpp, cC);
                 const double nq0 = cv[112 + r], np0 = cv[128 + r], nrn = cv[144 + r], ngn = cv[160 + r];
                 double t[6] = {dq * ya, dpp * yb, pk * dq, dq * yc, (nq0 - q) * nrn, (p - np0) * ngn}, s[6] = {0, 0, 0, 0, 0, 0};
                 dpp_guard(t);
