@@ -116,8 +116,21 @@ size_t gdml_lds_doubles(int N, int Dd) { const GdmlShape sh = gdml_shape(N); ret
 // set three times per geometry (5.9 MB from L2 at 30 atoms / 200 points, the kernel's bound); this reads 1.4 MB.
 // HN = half of the partner atoms the instantiation holds (four threads share the partners of one atom), 2 HN >= N.
 // MT = accumulator tiles per wavefront, NB = stage buffers (see gdml_tiles_per_wave, gdml_nb)
+// -DGDML_PHASE_CLOCK (variant library, tools/gdml_phases.py): wave 0 of workgroup 0 accumulates the shader cycles it spends in
+// every phase of its geometries into phase_clock[0..9]
+#ifdef GDML_PHASE_CLOCK
+__device__ unsigned long long *g_phase_clock = nullptr;
+#define GDML_TICK(slot) do { if (pc_on) { const unsigned long long now_ = clock64(); pc[slot] += now_ - pc_last; pc_last = now_; } } while (0)
+#else
+#define GDML_TICK(slot) do { } while (0)
+#endif
+
 template <int HN, int THREADS, int GDML_CH, int MT, int NB>
 __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, double *hess) {
+#ifdef GDML_PHASE_CLOCK
+    const bool pc_on = blockIdx.x == 0 && threadIdx.x == 0 && g_phase_clock != nullptr;
+    unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pc_last = clock64();
+#endif
     constexpr int GDML_MAX_TILES = MT;
     constexpr int nth = THREADS, nw = THREADS / 64;
     const int N = G.n_atoms, Dd = G.n_desc, Mt = G.n_train, X = 3 * N;
@@ -300,6 +313,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
     // k + 1 without a barrier: different data.
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wavefront's part of the first chunk has landed
     __syncthreads();
+    GDML_TICK(0);                                       // prologue
     for (int m0 = 0, buf = 0; m0 < Mt; m0 += GDML_CH, buf = NB == 2 ? buf ^ 1 : 0) {
         const int mc = min(GDML_CH, Mt - m0);
         const double *sxs = L.stage + buf * 2 * GDML_CH * Dd, *sal = sxs + GDML_CH * Dd;
@@ -309,20 +323,28 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
             __builtin_amdgcn_s_waitcnt(0x0F70);         // one buffer: this chunk was requested behind the previous chunk's
             __syncthreads();                            // last reader; everybody's part has landed
         }
+        GDML_TICK(1);                                   // copy requests of the next chunk
         gather_begin();
         auto gathers = [&] { sfor<0, QN>([&](auto ccc) { gather_partner(ccc, sxs, sal); }); };
         // four wavefronts: gathers between the row reductions and the scalar tail (coumarin 3.50 -> 3.35 ms per stage launch);
         // eight wavefronts: after the tail (the interleaved order costs the larger kernel 28 more spilled registers)
         if (THREADS == 256) row_scalars(m0, sxs, sal, gathers);
-        else { row_scalars(m0, sxs, sal, [] {}); gathers(); }
+        else { row_scalars(m0, sxs, sal, [] {}); GDML_TICK(2); gathers(); }
         gather_end();
+        GDML_TICK(3);                                   // (2: row reductions + scalar tail) 3: gathers
         __syncthreads();
+        GDML_TICK(4);                                   // barrier 1
         // (3) gradient terms of the chunk, (4) operand rows of the chunk
 #ifndef GDML_ABLATE_GRAD
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int d = tid + nth * j;
             if (d < Dd) {
+                // the exact rounding error of the addition (branch-free two-sum: the same value as the magnitude-ordered
+                // form, without the compare and selects)
+                // (round 4: all operands of a full chunk requested before the first term -- instead of two LDS round trips per
+                // training point, one point after the other -- costs 35 more spilled registers and 4 % of the launch: the loop
+                // stays rolled)
                 for (int mm = 0; mm < mc; ++mm) {
                     const double t = fma(L.fm[mm], sal[mm * Dd + d], -L.ea[mm] * (xown[j] - sxs[mm * Dd + d]));
                     // the exact rounding error of the addition (branch-free two-sum: the same value as the magnitude-ordered
@@ -347,8 +369,10 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                 }
             }
         }
+        GDML_TICK(5);                                   // gradient terms + operand rows
         if (NB == 2) __builtin_amdgcn_s_waitcnt(0x0F70);   // this wavefront's part of chunk k + 1 has landed
         __syncthreads();
+        GDML_TICK(6);                                   // copy wait + barrier 2
         if (NB == 1 && m0 + GDML_CH < Mt) stage_chunk(m0 + GDML_CH, 0);     // nobody reads the stage any more in this chunk
         // (5) [XJ ; -e AJ]^T [Z ; XJ] of the chunk on the matrix cores: all operands of the wavefront's tiles are requested
         //     first, then the MFMAs of the tiles run interleaved (one block, no wait between the products)
@@ -381,6 +405,7 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
             }
         }
 #endif
+        GDML_TICK(7);                                   // matrix-core phase
     }
     double red2[2] = {esum, ssum};
     block_sum<2>(red2, L.red);
@@ -422,31 +447,53 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         }
     }
     __syncthreads();
-    // atom-pair terms element by element, scale, write both triangles
+    // atom-pair terms element by element, scale, store.  A tile of the upper triangle goes out as it is (rows of 16
+    // consecutive doubles); its mirror image is TRANSPOSED through LDS and goes out in rows as well.  (Round 3 stored every
+    // value a second time by a scalar store with a stride of one matrix row -- 8 useful bytes per 64-byte sector: WRITE_SIZE
+    // 2.1 x the Hessian, profiles/r3_config5_hbm.json.)  The mirror holds the SAME values: the matrix is exactly symmetric.
+    {
+        double *tbuf = L.P + wave * (16 * 17);                  // the operand rows are dead; [16][17] doubles per wavefront
 #pragma unroll
-    for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
-        if (wave + sl * nw >= ntiles) continue;
-        const int y = 16 * tc_[sl] + li, b = y / 3, v = y - 3 * b;
+        for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
+            if (wave + sl * nw >= ntiles) continue;
+            const int y = 16 * tc_[sl] + li, b = y / 3, v = y - 3 * b;
+            const bool diag_tile = tr_[sl] == tc_[sl];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int xr = 16 * tr_[sl] + rg + 4 * qq, a = xr / 3, u = xr - 3 * a;
-            if (xr >= X || y >= X || (tr_[sl] == tc_[sl] && xr > y)) continue;
-            double fin;
-            if (a == b) fin = L.dg[9 * a + 3 * u + v];
-            else {
-                const int d = pair_index(a, b);
-                const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x;
-                const double du = L.pos[3 * a + u] - L.pos[3 * b + u], dv = L.pos[3 * a + v] - L.pos[3 * b + v];
-                fin = S * (x3 * du) * (x3 * dv) - (3.0 * g * x5 * du * dv - (u == v ? g * x3 : 0.0));
+            for (int qq = 0; qq < 4; ++qq) {
+                const int row = rg + 4 * qq, xr = 16 * tr_[sl] + row, a = xr / 3, u = xr - 3 * a;
+                double val = 0.0;
+                if (xr < X && y < X && !(diag_tile && xr > y)) {
+                    double fin;
+                    if (a == b) fin = L.dg[9 * a + 3 * u + v];
+                    else {
+                        const int d = pair_index(a, b);
+                        const double x = L.x[d], g = L.gx[d], x3 = x * x * x, x5 = x3 * x * x;
+                        const double du = L.pos[3 * a + u] - L.pos[3 * b + u], dv = L.pos[3 * a + v] - L.pos[3 * b + v];
+                        fin = S * (x3 * du) * (x3 * dv) - (3.0 * g * x5 * du * dv - (u == v ? g * x3 : 0.0));
+                    }
+                    val = (acc[sl][qq] + fin) * G.std;
+                    // written once, read by the monodromy kernel after the stage: non-temporal, so that the 65 KB per geometry do
+                    // not push the training set (read by every workgroup) out of the XCD's L2
+                    __builtin_nontemporal_store(val, &hess[(size_t)xr * X + y]);
+                }
+                tbuf[row * 17 + li] = val;
             }
-            const double val = (acc[sl][qq] + fin) * G.std;
-            // written once, read by the monodromy kernel after the stage: non-temporal, so that the 65 KB per geometry do not
-            // push the training set (read by every workgroup) out of the XCD's L2
-            __builtin_nontemporal_store(val, &hess[(size_t)xr * X + y]);
-            __builtin_nontemporal_store(val, &hess[(size_t)y * X + xr]);
+            wave_lds_fence();
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                // mirror element (row 16 tc + row, column 16 tr + li) = value (16 tr + li, 16 tc + row) of the tile
+                const int row = rg + 4 * qq, yy = 16 * tc_[sl] + row, xx = 16 * tr_[sl] + li;
+                const double val = tbuf[li * 17 + row];
+                if (yy < X && xx < X && (!diag_tile || li < row)) __builtin_nontemporal_store(val, &hess[(size_t)yy * X + xx]);
+            }
+            wave_lds_fence();
         }
     }
     __syncthreads();
+    GDML_TICK(8);                                       // epilogue: sums, Cartesian gradient, atom-pair terms, Hessian stores
+#ifdef GDML_PHASE_CLOCK
+    if (pc_on) { for (int i = 0; i < 10; ++i) g_phase_clock[i] += pc[i]; g_phase_clock[10] += 1; }
+#endif
     return energy;
 }
 
@@ -581,6 +628,12 @@ extern "C" int sc_gdml_eval(const sc_gdml_model *g, const double *r, int64_t n, 
     if (!launched) return sc_fail(SC_ERR_UNSUPPORTED, "sc_gdml_eval: no kernel for %d atoms", g->n_atoms);
     return sc_check_launch("sc_gdml_eval");
 }
+
+#ifdef GDML_PHASE_CLOCK
+extern "C" int sc_gdml_phase_clock(unsigned long long *buf) {       // device buffer of 11 counters, or NULL to switch off
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clock), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int sc_dense_grid(int64_t n) { return (int)(n < 512 ? (n > 0 ? n : 1) : 512); }
 
