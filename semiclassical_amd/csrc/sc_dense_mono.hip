@@ -419,8 +419,20 @@ __device__ __forceinline__ void lds_a_wait_all(sc_d2v (&a)[3]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
 }
 
+// -DGDML_PHASE_CLOCK (variant library, tools/mono_phases.py): wave 0 of workgroup 0 accumulates the shader cycles of the phases
+#ifdef GDML_PHASE_CLOCK
+__device__ unsigned long long *g_mono_clock = nullptr;
+#define MONO_TICK(slot) do { if (pc_on) { const unsigned long long now_ = clock64(); pc[slot] += now_ - pc_last; pc_last = now_; } } while (0)
+#else
+#define MONO_TICK(slot) do { } while (0)
+#endif
+
 template <int NT, int KT>
 __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) {
+#ifdef GDML_PHASE_CLOCK
+    const bool pc_on = blockIdx.x == 0 && threadIdx.x == 0 && g_mono_clock != nullptr;
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc_last = clock64();
+#endif
     extern __shared__ double2 smem2[];           // Hessian images [2 D + 2][HSB]
     constexpr int NSLAB = (2 * NT + 3) / 4, UPR = HSB / 2;
     constexpr int NDMA = (16 * NT * UPR + 255) / 256;          // LDS-DMA instructions per image and wavefront
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
         while (nitem < items && trajectory_of(nitem, nslab) >= A.st.n) nitem += gridDim.x;
         const double *Hnext_item = nitem < items ? A.hess + trajectory_of(nitem, nslab) * A.hess_stride : nullptr;
         double SX[NT][4], SY[NT][4], Xs[NT][4], Ys[NT][4], X0[NT][4], Y0[NT][4];
+        MONO_TICK(0);                                                        // item bookkeeping
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -503,6 +516,7 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
             }
 #pragma unroll 1
         for (int st = 0; st < 4; ++st, ++g) {
+            MONO_TICK(st == 0 ? 1 : 4);                                      // 1: loads of the tile's rows issued; 4: RK4 update
             // the image of this stage was requested during the previous stage's products: this wavefront's part has landed ...
             __builtin_amdgcn_s_waitcnt(0x0F70);
             // ... and everybody's; also: every wavefront is through the products of the previous stage, whose image the
@@ -510,6 +524,7 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
             __builtin_amdgcn_s_barrier();
             const double *Hnext = st < 3 ? Hg + (st + 1) * A.stage_stride : Hnext_item;
             const int nbuf = (g + 1) & 1;
+            MONO_TICK(2);                                                    // wait for the image (and, stage 0, the rows) + barrier
             d4 acc[NT];
 #pragma unroll
             for (int I = 0; I < NT; ++I) acc[I] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -535,10 +550,12 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
                     if (2 * kt < NDMA) request(Hnext, nbuf, 2 * kt);
                     if (2 * kt + 1 < NDMA) request(Hnext, nbuf, 2 * kt + 1);
                 }
+                // last stage: row 4 kt + rg (+ 2 D^2: the p block) of the next item's tile
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) a_cur[i] = a_nxt[i];
             }
+            MONO_TICK(3);                                                    // product loop (issue)
             const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0, c = (st == 2) ? dt : hh;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -550,6 +567,7 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
                     Ys[t][r] = fma(c, ky, Y0[t][r]);
                 }
         }
+        MONO_TICK(4);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -559,8 +577,15 @@ __global__ __launch_bounds__(256, 1) void dense_mono_mfma_slab_dma2(MonoArgs A) 
                     (My + (16 * t + 4 * r) * D)[toff] = fma(h6, SY[t][r], Y0[t][r]);
                 }
             }
+        MONO_TICK(5);                                                        // stores of the tile's rows (issue)
         item = nitem;
+#ifdef GDML_PHASE_CLOCK
+        if (pc_on) pc[7] += 1;
+#endif
     }
+#ifdef GDML_PHASE_CLOCK
+    if (pc_on) for (int i = 0; i < 8; ++i) g_mono_clock[i] = pc[i];
+#endif
 }
 
 template <int NT, int KT>
@@ -749,6 +774,12 @@ __global__ __launch_bounds__(256) void stage_consume_kernel(StageArgs2 A) {
 }
 
 }  // namespace
+
+#ifdef GDML_PHASE_CLOCK
+extern "C" int sc_mono_phase_clock(unsigned long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mono_clock), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int sc_stage_point(const sc_state *st, const sc_dense_scratch *sc, double dt, int32_t stage, double *r_out,
                               void *stream) {
