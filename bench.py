@@ -51,7 +51,7 @@ def algorithmic_bytes_per_traj_step(D):
 
 def wm_flops_per_traj_step(D, dp):
     """real flops (2 per multiply-add) of the Walton-Manolopoulos prefactor + correlation terms as the engine computes
-    them (csrc/sc_wm_small.hip header): Mq', Mp', Gt Mq', the two e x e Gram matrices, the
+    them (csrc/sc_wm_small.hip header; docs/NOTEBOOK.md section 4.2a): Mq', Mp', Gt Mq', the two e x e Gram matrices, the
     e x e complex elimination with D right-hand sides, eqns (57), (59), (70), the projected M', its elimination"""
     E = 2 * dp
     fma = (2 * D * D * E + D * D * E + 2 * E * E * D            # Mq', Mp' ; Tq ; G, S
@@ -327,7 +327,7 @@ def config5(dev, n, steps):
 def other_configs(dev):
     out = {}
     for key, fn, args in (("config1_n1000", config1, (1000, 100)), ("config1_n100000", config1, (100000, 50)),
-                          ("config3_wm_methylium", config3, (100000, 30)), ("methylium_hk", config3_hk, (100000, 30)),
+                          ("config3_wm_methylium", config3, (100000, 30)), ("methylium_hk", config3_hk, (100000, 200)),
                           ("config5_gdml30_share", config5, (1250, 5)), ("config5_gdml30_n10000", config5, (10000, 3))):
         try:
             out[key] = fn(dev, *args)
@@ -419,7 +419,7 @@ def main():
     torch.set_default_dtype(torch.float64)
     if args.config is not None:
         dev = torch.device("cuda", 0)
-        fn, fargs = {"1": (config1, (100000, 50)), "3": (config3, (100000, 30)), "3hk": (config3_hk, (100000, 30)), "5": (config5, (10000, 3))}[args.config]
+        fn, fargs = {"1": (config1, (100000, 50)), "3": (config3, (100000, 30)), "3hk": (config3_hk, (100000, 200)), "5": (config5, (10000, 3))}[args.config]
         print(json.dumps({f"config{args.config}": fn(dev, *fargs)}), flush=True)
         return
     from semiclassical_amd import distributed as D

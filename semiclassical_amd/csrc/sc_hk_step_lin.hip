@@ -14,7 +14,7 @@
 // Mapping as in sc_wm_small.hip: lane a of a 16-lane row holds row a of every matrix of its trajectory; Phi and the other
 // per-row constants sit in LDS (staged once per workgroup), uniform constants come from scalar registers.
 // Replaces hk_step_kernel<true> (every matrix in LDS, one 64-thread workgroup per trajectory) for the instantiated
-// shapes: config 3 (methylium, D = 12, d' = 6, n = 1e5) 1.78 -> see DESIGN.md.
+// shapes: config 3 (methylium, D = 12, d' = 6, n = 1e5) 1.78 -> 0.20 ms (docs/NOTEBOOK.md section 4.2).
 #include "sc_common.h"
 #include "sc_row16.h"
 

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         // RESET BARRIER -- unconditional, in every variant of this kernel (with or without the elimination).  It orders
         //   (a) thread 0's nextbuf[par] = drawn against the readfirstlane(nextbuf[par]) of every wave below: the value is
         //       the next trajectory index and goes straight into resource(trn), an unordered read addresses memory
-        //       outside the state (the GPU memory fault of round 2's tuning build);
+        //       outside the state (the GPU memory fault of round 2's tuning build, docs/NOTEBOOK.md section 8.2);
         //   (b) the resets of *weak and detbuf[par] above against the owner lanes' read-modify-writes in the elimination;
         //   (c) the previous trajectory's last uses of the pivot ring (rowbuf / pivrec) against block 0's first records.
         // Later blocks need no barrier: a wave owns every fourth pivot step, so when step s is published every wave has
@@ -556,7 +556,7 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
 #ifdef SC_TUNING
     // SC_WS=1: the wave-specialised schedule (one producer + three eliminator groups per CU).  Measured on MI355X at
     // n = 1e5, D = 60: 6.71 ms against 5.98 ms of this kernel -- the eliminations are bound by VALU issue, not by their
-    // latency, so giving them a CU of their own does not help.
+    // latency, so giving them a CU of their own does not help (docs/NOTEBOOK.md section 8).
     if (nr == 4 && step && a.mode == 0 && getenv("SC_WS")) return sc_launch_step_ws(a, s);
 #endif
     int sdgrid = grid;         // the energy partials belong to hk_modes_kernel: this kernel's grid is free

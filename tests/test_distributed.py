@@ -252,3 +252,32 @@ def test_torch_nccl_backend_on_the_visible_gpus(tmp_path):
     assert rc == 0
     r = json.loads(out.read_text())
     assert r["backend"] == "nccl" and r["world"] == n and r["ok"]
+
+
+@pytest.mark.gpu
+def test_driver_command_line_shares_batches_among_ranks(tmp_path):
+    """`python -m semiclassical_amd.driver dynamics input.json --gpus 2`: the command starts two rank processes itself; with
+    device sampling every rank draws ITS slice of each batch (same seed, first_index) -- the ensemble, and therefore the
+    result file, is that of the single-process run."""
+    g = cases.load("hk_as5_chi002")
+    model = tmp_path / "AS_model.dat"
+    rows = np.vstack((g["omega"] * 219474.63, 0.5 * g["omega"] * g["q0"] ** 2 * np.sign(g["q0"]), g["nac"],
+                      np.full(5, 0.02))).T
+    np.savetxt(model, rows)
+    res = {}
+    for gpus in (1, 2):
+        out = tmp_path / f"c{gpus}.npz"
+        task = {"task": "dynamics", "potential": {"type": "anharmonic AS", "model_file": str(model)},
+                "propagator": "HK", "batch_size": 700, "num_trajectories": 1400, "num_steps": 14, "time_step_fs": 0.04,
+                "results": {"correlations": str(out)}, "manual_seed": 11, "sampling": "device"}
+        inp = tmp_path / f"in{gpus}.json"
+        inp.write_text(json.dumps({"semi": [task]}))
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+        env["SC_DIST_BACKEND"] = "gloo"                      # two ranks on the one GPU of the test box
+        r = subprocess.run([sys.executable, "-m", "semiclassical_amd.driver", "dynamics", str(inp), "--gpus", str(gpus), "--cuda", "0"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[gpus] = dict(np.load(out))
+    assert int(res[2]["trajectories"]) == 1400
+    assert cases.rel_err(res[2]["autocorrelation"], res[1]["autocorrelation"]) < 1e-12
+    assert cases.rel_err(res[2]["ic_correlation"], res[1]["ic_correlation"]) < 1e-12

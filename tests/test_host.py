@@ -192,7 +192,7 @@ def test_dpp_hazards():
 
 def test_cursor_handover_is_fenced_in_the_source():
     """hk_step_sd_kernel hands the next trajectory index from thread 0 to the other wavefronts through LDS; the round-2 GPU
-    memory fault was a variant in which no barrier lay between the write and the reads.  The barrier
+    memory fault (docs/NOTEBOOK.md section 8.2) was a variant in which no barrier lay between the write and the reads.  The barrier
     must be unconditional (not inside a variant macro or a template branch) and sit between the two in the source."""
     import os
     import re

@@ -4,7 +4,7 @@
 # FETCH_SIZE x 2.000 on this image) applies to the fetch counter.
 set -e
 cd "$(dirname "$0")/.."
-tag=${1:-r3}
+tag=${1:-r4}
 export TMPDIR=/tmp
 out=gpurun_out/prof_hbm_$tag
 dst=gpurun_out/profiles_$tag

@@ -2,7 +2,7 @@
 # Everything under profiles/ for one round, in one session on the GPU box:  tools/round_profiles.sh r3
 set -e
 cd "$(dirname "$0")/.."
-tag=${1:-r3}
+tag=${1:-r4}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 dst=gpurun_out/profiles_$tag       # summaries (small): gpurun merges gpurun_out/ back, copy them to profiles/ afterwards
