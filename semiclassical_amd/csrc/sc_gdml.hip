@@ -447,12 +447,18 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         }
     }
     __syncthreads();
-    // atom-pair terms element by element, scale, store.  A tile of the upper triangle goes out as it is (rows of 16
-    // consecutive doubles); its mirror image is TRANSPOSED through LDS and goes out in rows as well.  (Round 3 stored every
-    // value a second time by a scalar store with a stride of one matrix row -- 8 useful bytes per 64-byte sector: WRITE_SIZE
-    // 2.1 x the Hessian, profiles/r3_config5_hbm.json.)  The mirror holds the SAME values: the matrix is exactly symmetric.
+    // atom-pair terms element by element, scale, store.  Round 3 stored every value twice from the accumulator layout -- the
+    // mirror image by scalar stores with a stride of one matrix row: WRITE_SIZE 2.1 x the Hessian (profiles/r3_config5_hbm.json);
+    // tiles stored in rows (mirror transposed through LDS) still write 1.56 x: a tile row is a 128-byte segment at an offset
+    // of 16 r bytes from a 64-byte sector (rows are 720 B at 30 atoms), every segment ends in partial sectors.  Now the whole
+    // symmetric matrix is assembled in LDS (the stage and operand buffers are dead) and streamed out linearly: whole sectors
+    // except at the two ends of a matrix (profiles/r4_config5_hbm.json).  Molecules whose matrix does not fit the dead
+    // buffers keep the tile stores.  The mirror holds the SAME values: the matrix is exactly symmetric.
     {
-        double *tbuf = L.P + wave * (16 * 17);                  // the operand rows are dead; [16][17] doubles per wavefront
+        const size_t room = (size_t)3 * GDML_CH * XP + (size_t)NB * 2 * GDML_CH * Dd;       // doubles from L.P to the end of the stage
+        const bool image = (size_t)X * X + 1 <= room;
+        double *img = L.P + (((uintptr_t)L.P >> 3) & 1);           // 16-byte aligned
+        double *tbuf = L.P + wave * (16 * 17);                  // tile path: [16][17] doubles per wavefront
 #pragma unroll
         for (int sl = 0; sl < GDML_MAX_TILES; ++sl) {
             if (wave + sl * nw >= ntiles) continue;
@@ -472,21 +478,28 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                         fin = S * (x3 * du) * (x3 * dv) - (3.0 * g * x5 * du * dv - (u == v ? g * x3 : 0.0));
                     }
                     val = (acc[sl][qq] + fin) * G.std;
+                    if (image) { img[xr * X + y] = val; img[y * X + xr] = val; }
                     // written once, read by the monodromy kernel after the stage: non-temporal, so that the 65 KB per geometry do
                     // not push the training set (read by every workgroup) out of the XCD's L2
-                    __builtin_nontemporal_store(val, &hess[(size_t)xr * X + y]);
+                    else __builtin_nontemporal_store(val, &hess[(size_t)xr * X + y]);
                 }
-                tbuf[row * 17 + li] = val;
+                if (!image) tbuf[row * 17 + li] = val;
             }
-            wave_lds_fence();
+            if (!image) {
+                wave_lds_fence();
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                // mirror element (row 16 tc + row, column 16 tr + li) = value (16 tr + li, 16 tc + row) of the tile
-                const int row = rg + 4 * qq, yy = 16 * tc_[sl] + row, xx = 16 * tr_[sl] + li;
-                const double val = tbuf[li * 17 + row];
-                if (yy < X && xx < X && (!diag_tile || li < row)) __builtin_nontemporal_store(val, &hess[(size_t)yy * X + xx]);
+                for (int qq = 0; qq < 4; ++qq) {
+                    // mirror element (row 16 tc + row, column 16 tr + li) = value (16 tr + li, 16 tc + row) of the tile
+                    const int row = rg + 4 * qq, yy = 16 * tc_[sl] + row, xx = 16 * tr_[sl] + li;
+                    const double val = tbuf[li * 17 + row];
+                    if (yy < X && xx < X && (!diag_tile || li < row)) __builtin_nontemporal_store(val, &hess[(size_t)yy * X + xx]);
+                }
+                wave_lds_fence();
             }
-            wave_lds_fence();
+        }
+        if (image) {
+            __syncthreads();
+            for (int e = tid; e < X * X; e += nth) __builtin_nontemporal_store(img[e], &hess[e]);
         }
     }
     __syncthreads();
