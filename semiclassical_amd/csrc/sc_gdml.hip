@@ -240,14 +240,23 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
         const int mm = min(wave, GDML_CH - 1);
         const bool has = wave < min(GDML_CH, Mt - m0);
         double s2 = 0.0, sa = 0.0;
+        {
+            // two elements per trip (the six LDS reads of a trip are requested together; a trip used to wait for three reads per
+            // element, one element after the other), two accumulator pairs
+            double s2b = 0.0, sab = 0.0;
 #ifdef GDML_ABLATE_ROWRED
-        for (int d = lane; d < 64; d += 64) {
+            for (int d = lane; d < 64; d += 128) {
 #else
-        for (int d = lane; d < Dd; d += 64) {
+            for (int d = lane; d < Dd; d += 128) {
 #endif
-            const double xd = L.x[d] - sxs[mm * Dd + d];
-            s2 = fma(xd, xd, s2);
-            sa = fma(xd, sal[mm * Dd + d], sa);
+                const int d2 = d + 64, dc = min(d2, Dd - 1);
+                const double x0 = L.x[d], xs0 = sxs[mm * Dd + d], a0 = sal[mm * Dd + d];
+                const double x1 = L.x[dc], xs1 = sxs[mm * Dd + dc], a1 = sal[mm * Dd + dc];
+                const double xd0 = x0 - xs0, xd1 = d2 < Dd ? x1 - xs1 : 0.0;
+                s2 = fma(xd0, xd0, s2); sa = fma(xd0, a0, sa);
+                s2b = fma(xd1, xd1, s2b); sab = fma(xd1, a1, sab);
+            }
+            s2 += s2b; sa += sab;
         }
         s2 = wave_sum(s2); sa = wave_sum(sa);
         between();
@@ -345,14 +354,21 @@ __device__ double gdml_eval_device(const sc_gdml_model &G, const GdmlLds &L, dou
                 // (round 4: all operands of a full chunk requested before the first term -- instead of two LDS round trips per
                 // training point, one point after the other -- costs 35 more spilled registers and 4 % of the launch: the loop
                 // stays rolled)
-                for (int mm = 0; mm < mc; ++mm) {
-                    const double t = fma(L.fm[mm], sal[mm * Dd + d], -L.ea[mm] * (xown[j] - sxs[mm * Dd + d]));
+                auto add_term = [&](double t) {
                     // the exact rounding error of the addition (branch-free two-sum: the same value as the magnitude-ordered
                     // form, without the compare and selects)
                     const double sn = gacc[j] + t, bb = sn - gacc[j];
                     gcomp[j] += (gacc[j] - (sn - bb)) + (t - bb);
                     gacc[j] = sn;
+                };
+                int mm = 0;
+                for (; mm + 1 < mc; mm += 2) {              // two training points per trip: eight LDS reads in flight instead of four
+                    const double f0 = L.fm[mm], e0 = L.ea[mm], a0 = sal[mm * Dd + d], x0 = sxs[mm * Dd + d];
+                    const double f1 = L.fm[mm + 1], e1 = L.ea[mm + 1], a1 = sal[(mm + 1) * Dd + d], x1 = sxs[(mm + 1) * Dd + d];
+                    add_term(fma(f0, a0, -e0 * (xown[j] - x0)));
+                    add_term(fma(f1, a1, -e1 * (xown[j] - x1)));
                 }
+                if (mm < mc) add_term(fma(L.fm[mm], sal[mm * Dd + d], -L.ea[mm] * (xown[j] - sxs[mm * Dd + d])));
             }
         }
 #endif
