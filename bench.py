@@ -63,7 +63,7 @@ def wm_flops_per_traj_step(D, dp):
     return 2 * fma
 
 
-def profiled_traffic(n, dim, live_ms):
+def profiled_traffic(n, dim, live_ms, steps_per_launch=1):
     """HBM bytes per step-kernel launch from the newest committed rocprofv3 PMC passes (profiles/rN_hbm_traffic.json) --
     but only if that profile still describes THIS run: same workload, same kernel, and the kernel-trace summary of the same
     profiling session (profiles/rN_bench_kernel_stats.csv) gives the launch pair (step kernel + modes pre-pass) within 5 % of
@@ -83,8 +83,10 @@ def profiled_traffic(n, dim, live_ms):
             if t["workload"]["ntraj"] != n or t["workload"]["dim"] != dim:
                 continue
             kernel = t["workload"]["kernel"]
-            if "hk_step_sd_kernel<4, 4, true, true>" not in kernel:
-                reasons.append(f"profiles/{name} profiled {kernel}, not the kernel of this run")
+            per = int(t.get("steps_per_launch", 1))
+            want = f"hk_step_sd_kernel<4, 4, true, true, {steps_per_launch}>"
+            if want not in kernel or per != steps_per_launch:
+                reasons.append(f"profiles/{name} profiled {kernel}, not the kernel of this run ({want})")
                 continue
             stats = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv")
             avg = {}
@@ -92,14 +94,14 @@ def profiled_traffic(n, dim, live_ms):
                 for row in csv.reader(f):
                     if len(row) >= 4 and row[0] != "Name" and not row[0].startswith("#"):
                         avg[row[0]] = float(row[3]) / 1e3
-            step = next(v for k, v in avg.items() if "hk_step_sd_kernel<4, 4, true, true>" in k)
-            modes = next(v for k, v in avg.items() if "hk_modes_kernel" in k)
+            step = next(v for k, v in avg.items() if want in k) / per
+            modes = next(v for k, v in avg.items() if ("hk_modes_multi_kernel" if per > 1 else "hk_modes_kernel") in k) / per
             if abs(step + modes - live_ms) > 0.05 * live_ms:
-                reasons.append(f"profiles/{name}: its session measured {step + modes:.3f} ms per launch pair, this run {live_ms:.3f} ms "
+                reasons.append(f"profiles/{name}: its session measured {step + modes:.3f} ms per time step, this run {live_ms:.3f} ms "
                           "(more than 5 % apart: the profile is stale for this build or box)")
                 continue
             return t["traffic_bytes_per_launch"], (f"profiles/{name} (FETCH_SIZE calibrated + WRITE_SIZE, separate passes; kernel-trace of "
-                                                   f"that session: {step + modes:.3f} ms per launch pair, this run {live_ms:.3f} ms)")
+                                                   f"that session: {step + modes:.3f} ms per time step, this run {live_ms:.3f} ms)")
         except (OSError, KeyError, ValueError, StopIteration) as err:
             reasons.append(f"profiles/{name}: {type(err).__name__} {err}")
             continue
@@ -399,6 +401,7 @@ def parse_args(argv=None):
                     help="trajectories of the whole job, sharded over the GPUs (default at --gpus 8: 10^6 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration lines and the 2000-step run")
+    ap.add_argument("--no-pairs", action="store_true", help="A/B: one step-kernel launch per time step instead of two steps per visit")
     ap.add_argument("--config", choices=["1", "3", "3hk", "5"], default=None,
                     help="run ONLY that BASELINE configuration's side measurement (for one rocprofv3 summary per configuration: "
                          "1 = 5-mode AS at n = 1e5, 3 = methylium WM at n = 1e5, 5 = 30-atom sGDML at n = 1e4) and print its JSON")
@@ -447,6 +450,7 @@ def main():
     # initial conditions are sampled on the device (sc_sample_initial): every rank draws ITS slice of one global
     # ensemble -- deviate j of global trajectory i depends on (seed, i, j) only, not on the number of ranks
     first = D.shard_slice(n_total, rank, world).start if args.ntraj_total is not None else rank * n
+    prop.pair_steps = not args.no_pairs
     prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, ntraj_total=n_total, seed=1234, first_index=first)
 
     K, W = args.steps, args.warmup
@@ -495,7 +499,8 @@ def main():
         kern_ms = float(np.mean(step_ms))
         abytes = algorithmic_bytes_per_traj_step(dim) * n
         achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_source = profiled_traffic(n, dim, kern_ms)
+        per = 2 if (prop._multi is not None and K >= 2) else 1        # run() advanced two time steps per launch (sc_hk_step_multi)
+        traffic, traffic_source = profiled_traffic(n, dim, kern_ms, per)
         out = {
             "metric": "trajectory-steps/sec + wall-time to converged C(t), anharmonic-AS D=60",
             "value": n_total * K / wall, "unit": "trajectory-steps/s",
@@ -514,9 +519,16 @@ def main():
                        "sharding": f"{world} x {n} trajectories, one RCCL all-reduce of 4*K doubles per flush"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "hk_step_sd_kernel<4,4,true,true> (+ its hk_modes_kernel pre-pass, same event bracket)",
+                         "kernel": (f"hk_step_sd_kernel<4,4,true,true,{per}> (+ its modes pre-pass, same event bracket)"
+                                    + ("; one launch advances every trajectory by TWO time steps (the second step's reads come from "
+                                       "the memory-side cache): achieved, traffic, kernel_ms and the algorithmic bytes are per TIME STEP, "
+                                       "i.e. per half launch" if per == 2 else "")),
+                         "steps_per_launch": per,
                          "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": abytes},
+                         "algorithmic_bytes_per_launch": abytes,
+                         "also_bound_by": ("FP64 VALU issue in the elimination: with the second step's reads out of the way the streaming "
+                                           "phase alone takes 2.94 ms per step, the elimination-bound launch 3.8 (profiles/r4_sd_phases.txt)"
+                                           if per == 2 else None)},
             "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
         }
         if world == 1:

@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        14
+#define SC_ABI_VERSION        15
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -235,6 +235,31 @@ int sc_sample_initial(const sc_state *st, const double *ilz, const double *z0, i
  *   mode 0: step + prefactor;  mode 1: prefactor only with tracker initialisation (t = 0, propagators.py:631). */
 int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk,
                double dt, int32_t mode, double *energy_partials, void *stream);
+
+/* TWO consecutive time steps per visit of a trajectory (round 4): the same arithmetic as two calls of sc_hk_step, for the
+ * separable / diagonal-width fast path with 16 < D <= 64 on the tiled storage order (sc_hk_step_multi_supported).  A workgroup
+ * streams a trajectory's monodromy blocks, applies step k, stores them, eliminates -- and streams the SAME trajectory again for
+ * step k + 1: these loads hit the L2 / memory-side cache instead of HBM (profiles/r4_revisit.txt), one of the four HBM transfers
+ * of two time steps is gone.  Results are bit-identical to two sc_hk_step calls (tests/test_hk_multi_gpu.py).  Measured at
+ * D = 60, n = 1e5: 4.38 instead of 4.55 ms per step -- the streaming phase alone drops from 4.39 to 2.94 ms per step, but the
+ * elimination (FP64 VALU issue) then bounds the kernel at 3.8-4.4 ms (profiles/r4_sd_phases.txt).
+ *   ms->work    [2][n][4][D]   row propagators of both sub-steps (scratch)
+ *   ms->qp_mid  [n][2D], act_mid [n], c2_mid [n] complex, sgn_mid [n]: the state BETWEEN the two steps -- what sc_hk_correlate of
+ *               the second time step reads (pass an sc_state whose qp / act / c2 / sgn point to them)
+ *   ms->unrepaired   one int32 on the device, zeroed by the caller.  The fix-up of a weak in-block pivot (sc_state.flags) needs
+ *               the blocks the determinant belongs to; for the FIRST sub-step they have moved on.  The kernel counts such
+ *               determinants here: non-zero after the call = the intermediate determinants (and everything derived from them)
+ *               are not reliable, redo the two steps from a saved state with sc_hk_step.  Monodromy blocks that are
+ *               diagonal (separable potential from M(0) = 1) cannot have weak pivots; HermanKlukPropagator.run() takes this
+ *               entry point only then.
+ *   energy_partials [2][sc_step_grid()]: sums of T+V at the k4 stage of either step (two sc_energy_guard calls). */
+typedef struct sc_multi_scratch {
+    double *work, *qp_mid, *act_mid, *c2_mid, *sgn_mid;
+    int32_t *unrepaired;
+} sc_multi_scratch;
+int sc_hk_step_multi_supported(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk);
+int sc_hk_step_multi(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_multi_scratch *ms,
+                     double dt, double *energy_partials, void *stream);
 
 /* out[i] = <qp[i] , G_bra | qk,pk,G_ket> for i < n  (complex).  propagators.py:181-240 with a single ket. */
 int sc_overlap(const sc_overlap_consts *oc, const double *qp, int64_t n, double *out, void *stream);

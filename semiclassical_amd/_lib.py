@@ -64,6 +64,11 @@ class sc_gdml_model(C.Structure):
                 ("inv_mass", c_double_p)]
 
 
+class sc_multi_scratch(C.Structure):
+    _fields_ = [("work", c_double_p), ("qp_mid", c_double_p), ("act_mid", c_double_p), ("c2_mid", c_double_p),
+                ("sgn_mid", c_double_p), ("unrepaired", C.c_void_p)]
+
+
 class sc_dense_scratch(C.Structure):
     _fields_ = [("hess", c_double_p), ("kprev", c_double_p), ("ksum", c_double_p), ("ssum", c_double_p)]
 
@@ -73,9 +78,9 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 14              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 15              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
-           sc_dense_scratch)
+           sc_dense_scratch, sc_multi_scratch)
 
 SIGNATURES = {
     "sc_version": (C.c_int, []),
@@ -92,6 +97,9 @@ SIGNATURES = {
                                     C.c_int64, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_void_p]),
     "sc_hk_step": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), C.c_double, C.c_int32,
                              c_double_p, C.c_void_p]),
+    "sc_hk_step_multi_supported": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts)]),
+    "sc_hk_step_multi": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), P(sc_multi_scratch), C.c_double, c_double_p,
+                                   C.c_void_p]),
     "sc_overlap": (C.c_int, [P(sc_overlap_consts), c_double_p, C.c_int64, c_double_p, C.c_void_p]),
     "sc_nac_initial": (C.c_int, [P(sc_nac_consts), c_double_p, C.c_int64, c_double_p, C.c_void_p]),
     "sc_hk_correlate": (C.c_int, [P(sc_state), P(sc_overlap_consts), P(sc_nac_consts), c_double_p, c_double_p,

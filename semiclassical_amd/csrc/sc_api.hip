@@ -32,6 +32,7 @@ extern "C" int sc_struct_size(const char *name) {
 #define SC_SIZE_OF(T) if (!strcmp(name, #T)) return (int)sizeof(T);
     SC_SIZE_OF(sc_potential) SC_SIZE_OF(sc_state) SC_SIZE_OF(sc_hk_consts) SC_SIZE_OF(sc_overlap_consts)
     SC_SIZE_OF(sc_nac_consts) SC_SIZE_OF(sc_wm_consts) SC_SIZE_OF(sc_gdml_model) SC_SIZE_OF(sc_dense_scratch)
+    SC_SIZE_OF(sc_multi_scratch)
 #undef SC_SIZE_OF
     return -1;
 }

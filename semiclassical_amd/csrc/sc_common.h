@@ -179,6 +179,7 @@ __device__ __forceinline__ void rk4_pair(double &u, double &v, double im, double
 
 #define SC_SEP16_MAX_D 12    // D <= 12: hk_step_sep16_kernel (four trajectories per wavefront); 13 .. 16: hk_step_w16_kernel
 int sc_launch_step_sep16(const StepArgs &a, int grid_entries, hipStream_t s);   // sc_hk_step_sep16.hip: 1 launched, 0 not taken
+int sc_launch_step_sd_multi(const StepArgs &a, const sc_multi_scratch &ms, hipStream_t s);    // sc_hk_step_sd.hip: two steps per visit
 int sc_launch_step_lin(const StepArgs &a, int grid, hipStream_t s);   // sc_hk_step_lin.hip: 1 launched, 0 shape not built
 
 // host-side error plumbing (sc_api.hip)

@@ -286,12 +286,14 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
 #ifdef SC_TUNING
         if (getenv("SC_NO_WAVE_KERNEL")) small = false;      // the 256-thread kernel is forced: it needs flags and cursor
 #endif
-        // flags[n]: trajectories flagged in this step, flags[n + 1]: trajectory cursor of the fast kernel
-        if (!small && st->flags && hipMemsetAsync(st->flags + st->n, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
-            return sc_check_launch("sc_hk_step (flag counter)");
-        const int rc = sc_launch_step_sd(a, (hipStream_t)stream);
-        if (rc != SC_OK || !st->flags || small || (dbg & 0x100)) return rc;
-        mode |= 0x200;      // fully pivoted fix-up of the trajectories the fast path flagged (normally none)
+        if (!(mode & 0x400)) {      // 0x400 (internal, sc_hk_step_multi): the fast kernels have run, only the fix-up is wanted
+            // flags[n]: trajectories flagged in this step, flags[n + 1]: trajectory cursor of the fast kernel
+            if (!small && st->flags && hipMemsetAsync(st->flags + st->n, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
+                return sc_check_launch("sc_hk_step (flag counter)");
+            const int rc = sc_launch_step_sd(a, (hipStream_t)stream);
+            if (rc != SC_OK || !st->flags || small || (dbg & 0x100)) return rc;
+        }
+        mode = (mode & ~0x400) | 0x200;      // fully pivoted fix-up of the trajectories the fast path flagged (normally none)
     }
     const size_t DD = (size_t)D * D, dp = hk->dprime;
     size_t doubles = 32 + 2 + 2 * ((4 * D + 1) & ~1) + 2 * dp * dp + (hk->diag ? 0 : 2 * D * dp);
@@ -330,4 +332,32 @@ extern "C" int sc_hk_step(const sc_potential *pot, const sc_state *st, const sc_
         hipLaunchKernelGGL(hk_step_kernel<false>, dim3(grid), dim3(threads), lds, s, a);
     }
     return sc_check_launch("sc_hk_step");
+}
+
+// ---- two time steps per visit (include/semiclassical_hip.h: sc_hk_step_multi) ----
+extern "C" int sc_hk_step_multi_supported(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk) {
+    if (!pot || !st || !hk) return 0;
+    const bool sep = pot->kind == SC_POT_MORSE || pot->kind == SC_POT_HARMONIC_SEP || pot->kind == SC_POT_EPS_MORSE;
+    return sep && hk->diag && hk->dprime == st->dim && pot->dim == st->dim && hk->dim == st->dim && st->dim > 16 && st->dim <= 64 &&
+           st->mono_layout == SC_MONO_TILED16 && st->work && st->flags ? 1 : 0;
+}
+
+extern "C" int sc_hk_step_multi(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_multi_scratch *ms,
+                                double dt, double *energy_partials, void *stream) {
+    if (!pot || !st || !hk || !ms) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step_multi: null argument");
+    if (!ms->work || !ms->qp_mid || !ms->act_mid || !ms->c2_mid || !ms->sgn_mid || !ms->unrepaired)
+        return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_step_multi: null scratch field");
+    if (!sc_hk_step_multi_supported(pot, st, hk))
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_step_multi: needs a separable potential, diagonal width matrices, 16 < D <= 64, the tiled "
+                       "storage order (sc_mono_convert) and sc_state.work / flags (use sc_hk_step)");
+    if (st->n <= 0) return SC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // flags[n]: trajectories flagged in the LAST sub-step, flags[n + 1]: trajectory cursor of the block kernel
+    if (hipMemsetAsync(st->flags + st->n, 0, 2 * sizeof(int32_t), s) != hipSuccess) return sc_check_launch("sc_hk_step_multi (flag counter)");
+    const int grid = sc_step_grid(st->n, st->dim);
+    StepArgs a{*pot, *st, *hk, dt, 0, energy_partials, 2 * grid};
+    int rc = sc_launch_step_sd_multi(a, *ms, s);
+    if (rc != SC_OK) return rc;
+    // weak in-block pivots of the LAST sub-step (normally none): fully pivoted fix-up from the final blocks, as in sc_hk_step
+    return sc_hk_step(pot, st, hk, dt, 0x400, nullptr, stream);
 }

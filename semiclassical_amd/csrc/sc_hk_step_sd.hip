@@ -55,6 +55,12 @@
 #ifndef SC_SD_LOAD_AUX
 #define SC_SD_LOAD_AUX 2
 #endif
+#ifndef SC_SD_MULTI_LOAD_AUX            // first sub-step of a multi-step visit
+#define SC_SD_MULTI_LOAD_AUX 2
+#endif
+#ifndef SC_SD_MULTI_MID_AUX             // stores of an intermediate sub-step, loads of the following one
+#define SC_SD_MULTI_MID_AUX 0
+#endif
 #ifndef SC_SD_STORE_AUX
 #define SC_SD_STORE_AUX 2
 #endif
@@ -81,8 +87,45 @@ typedef unsigned int sc_v2u __attribute__((ext_vector_type(2)));
 // row mapping trow = 4 w + j a wave instruction then covers 512 contiguous bytes, the four waves one tile plane, and
 // the workgroup walks the 4 D^2 doubles of the trajectory linearly -- measured 14 % more streaming bandwidth than the
 // 128-byte row segments of the row-major layout (tools/micro/stream_patterns.hip).
-template <int NR, int MINW, bool STEP, bool TILED>
-__global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
+//
+// KS > 1 (round 4, sc_hk_step_multi): KS consecutive time steps per VISIT of a trajectory.  The blocks are stored after every
+// sub-step as before, but the next sub-step of the same trajectory follows at once, by the same threads at the same addresses:
+// its loads hit the L2 / the 256 MB memory-side cache (1024 workgroups hold 118 MB between two sub-steps) instead of HBM
+// (tools/micro/revisit.hip, profiles/r4_revisit.txt: a second read-modify-write visit costs 1.1 ms instead of 4.6).  The
+// intermediate stores and loads are plain (cacheable), the first load and the last store of a visit non-temporal (the first
+// load plain, the last store plain: same time).  Measured (profiles/r4_sd_phases.txt): WITHOUT the elimination the pair kernel
+// streams at 2.94 ms per step (one step per visit: 4.39); WITH it 4.40 against 4.63 -- in this mode the kernel is bound by the
+// elimination (26-36 us of a workgroup's 39-50 us per item; FP64 VALU issue, 64-71 % busy in the SQ counters), no longer by HBM.
+// Load depth 2 / 1.5, earlier prefetch, wave priority for the owner of the next pivot, an early request of thread 0's previous
+// determinant: each measured, none faster (spills at 128 VGPRs, or no effect).  Row
+// propagators of sub-step ks: M.work[ks][n][4][D] (hk_modes_multi_kernel); determinant and branch sign after sub-step
+// ks < KS - 1: M.c2_mid / M.sgn_mid [ks][n], after the last one: the state's own arrays.
+struct MultiArgs {
+    const double *work;        // [KS][n][4][D]; KS = 1: unused (st.work)
+    double *c2_mid, *sgn_mid;  // [KS - 1][n]
+    int *unrepaired;           // counts determinants of INTERMEDIATE sub-steps whose in-block pivots were weak: the blocks have
+                               // moved on by the time a fix-up launch could recompute them (sc_hk_step_multi's contract)
+};
+
+// -DSD_PHASE_CLOCK (variant library, tools/sd_phases.py): lane 0 of every wave of workgroups 0 and 512 writes the 100 MHz wall clock
+// at six points of every item (trajectory sub-step) to g_sd_clock[2][4][256][6] -- raw time stamps, no accumulators in registers
+#ifdef SD_PHASE_CLOCK
+__device__ unsigned long long *g_sd_clock = nullptr;
+#define SD_TICK(i)                                                                                                       \
+    do {                                                                                                                 \
+        if (pc_blk >= 0 && pc_item < 256 && (threadIdx.x & 63) == 0)                                                     \
+            g_sd_clock[((pc_blk * 4 + (threadIdx.x >> 6)) * 256 + pc_item) * 6 + (i)] = wall_clock64();                  \
+    } while (0)
+#else
+#define SD_TICK(i) do { } while (0)
+#endif
+
+template <int NR, int MINW, bool STEP, bool TILED, int KS = 1>
+__global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, MultiArgs MA) {
+#ifdef SD_PHASE_CLOCK
+    const int pc_blk = g_sd_clock == nullptr ? -1 : (blockIdx.x == 0 ? 0 : (blockIdx.x == 512 ? 1 : -1));
+    int pc_item = 0;
+#endif
     __shared__ double prop[4 * 64];          // P_a = (p11, p12, p21, p22) of row a
     __shared__ double scl[4 * 64];           // st, 1/st, si, 1/si
     __shared__ cplx rowbuf[16][64];
@@ -128,7 +171,13 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
     // barrier of the elimination.  Without sc_state.flags: static stride.
     int *cursor = A.st.flags ? A.st.flags + A.st.n + 1 : nullptr;
     int64_t trn = 0;
-    for (int64_t tr = blockIdx.x; tr < A.st.n; tr = trn, seq0 += 4, par ^= 1) {
+    for (int64_t tr = blockIdx.x; tr < A.st.n; tr = trn) {
+      sfor<0, KS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;                 // sub-step of this visit
+        constexpr int aux_load = ks == 0 ? (KS > 1 ? SC_SD_MULTI_LOAD_AUX : SC_SD_LOAD_AUX) : SC_SD_MULTI_MID_AUX;
+        constexpr int aux_store = ks == KS - 1 ? SC_SD_STORE_AUX : SC_SD_MULTI_MID_AUX;
+        // what is streamed next: the next sub-step of this trajectory, or the first one of the next trajectory
+        constexpr int ksn = ks + 1 < KS ? ks + 1 : 0;
         int *weak = &weakbuf[par];
         // Everything derived from the thread index is recomputed per trajectory: hipcc otherwise keeps those values live
         // across the elimination, spills them, and reloads them one by one behind s_waitcnt vmcnt(0) in the load stream
@@ -140,7 +189,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         if (tl == 0) *weak = SC_SD_FORCE_FIXUP;             // 1: variant library that hands every trajectory to the fallback
         if (tl < 16) detbuf[par][tl] = c_make(1.0, 0.0);
         int drawn = 0;
-        if (cursor && tl == 0) drawn = atomicAdd(cursor, 1);
+        if (ks == 0 && cursor && tl == 0) drawn = atomicAdd(cursor, 1);
         const int pk = tl >> 6, pa = tl & 63;               // thread -> (row of P, mode) of st.work
 
         // ---------------- phase B ----------------
@@ -173,15 +222,15 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         auto resource = [&](int64_t t) {
             return __builtin_amdgcn_make_buffer_rsrc(A.st.mono + t * 4 * (int64_t)Dl * Dl, 0, 32 * Dl * Dl, 0x00020000);
         };
-        auto load_slot = [&](auto rac, int64_t t) {
-            constexpr int ra = decltype(rac)::value;
+        auto load_slot = [&](auto rac, int64_t t, auto auxc) {
+            constexpr int ra = decltype(rac)::value, aux = decltype(auxc)::value;
             const __amdgpu_buffer_rsrc_t rs = resource(t);
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
                 const int vofs = voffset(ra, rb), base = tile_base(ra, rb), plane = plane_bytes(ra, rb);
 #pragma unroll
                 for (int pl = 0; pl < 4; ++pl) {
-                    const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, vofs, base + pl * plane, TILED ? SC_SD_LOAD_AUX : 0);
+                    const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, vofs, base + pl * plane, TILED ? aux : 0);
                     raw[ra & 1][pl][rb] = __hiloint2double((int)v.y, (int)v.x);
                 }
             }
@@ -197,9 +246,11 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                 }
             }
         };
-        auto first_requests = [&](int64_t t) {           // P_a and row slot 0 of trajectory t
-            if (!SC_SD_DIRECT_P && do_step && pa < Dl) prv = A.st.work[(t * 4 + pk) * (int64_t)Dl + pa];
-            load_slot(std::integral_constant<int, 0>(), t);
+        auto first_requests = [&](int64_t t, auto ksnc) {    // P_a and row slot 0 of sub-step ksnc of trajectory t
+            constexpr int k2 = decltype(ksnc)::value;
+            const double *wk = KS > 1 ? MA.work + (int64_t)k2 * A.st.n * 4 * Dl : A.st.work;
+            if (!SC_SD_DIRECT_P && do_step && pa < Dl) prv = wk[(t * 4 + pk) * (int64_t)Dl + pa];
+            load_slot(std::integral_constant<int, 0>(), t, std::integral_constant<int, (k2 == 0 ? (KS > 1 ? SC_SD_MULTI_LOAD_AUX : SC_SD_LOAD_AUX) : SC_SD_MULTI_MID_AUX)>());
         };
         auto finish_slot = [&](auto rac) {
             constexpr int ra = decltype(rac)::value;
@@ -221,7 +272,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                     for (int pl = 0; pl < 4; ++pl) {
                         sc_v2u v;
                         v.x = (unsigned)__double2loint(out[pl]); v.y = (unsigned)__double2hiint(out[pl]);
-                        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vofs, base + pl * plane, TILED ? SC_SD_STORE_AUX : 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vofs, base + pl * plane, TILED ? aux_store : 0);
                     }
                 }
                 const int bl = (16 * rb + tjl) & 63;
@@ -236,10 +287,11 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         };
         // sched_barrier: the stages are scheduled one by one (hipcc otherwise interleaves the stages of this branch-free
         // block until the raw values of three slots are live at once, and spills)
-        if (first || !SC_SD_XPREFETCH || NR == 1) first_requests(tr);
+        SD_TICK(0);
+        if (first || !SC_SD_XPREFETCH || NR == 1) first_requests(tr, ksc);
         first = false;
         __builtin_amdgcn_sched_barrier(0);
-        if (NR > 1 && SC_SD_DEPTH > 1) load_slot(std::integral_constant<int, (NR > 1 ? 1 : 0)>(), tr);
+        if (NR > 1 && SC_SD_DEPTH > 1) load_slot(std::integral_constant<int, (NR > 1 ? 1 : 0)>(), tr, std::integral_constant<int, aux_load>());
         __builtin_amdgcn_sched_barrier(0);
         if (do_step && !SC_SD_DIRECT_P) {
             // every wave is past the previous trajectory's phase B (the elimination barriers lie in between), so prop
@@ -249,8 +301,8 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         }
         sfor<0, NR>([&](auto rac) {
             constexpr int ra = decltype(rac)::value;
-            if (SC_SD_DEPTH == 1 && ra > 0) load_slot(rac, tr);
-            if (SC_SD_DEPTH > 1 && ra + 1 < NR && ra > 0) load_slot(std::integral_constant<int, (ra + 1 < NR ? ra + 1 : 0)>(), tr);
+            if (SC_SD_DEPTH == 1 && ra > 0) load_slot(rac, tr, std::integral_constant<int, aux_load>());
+            if (SC_SD_DEPTH > 1 && ra + 1 < NR && ra > 0) load_slot(std::integral_constant<int, (ra + 1 < NR ? ra + 1 : 0)>(), tr, std::integral_constant<int, aux_load>());
             __builtin_amdgcn_sched_barrier(0);
             finish_slot(rac);
             __builtin_amdgcn_sched_barrier(0);
@@ -260,7 +312,8 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         // phase ablation (tools/phase_timing.py) is a COMPILE-time switch of a variant library: a run-time flag here costs the
         // kernel 148 B/lane of scratch and 30 % of its speed
         constexpr bool skip_lu = SC_SD_ABLATE_LU != 0;
-        if (cursor && tl == 0) nextbuf[par] = drawn;
+        SD_TICK(1);
+        if (ks == 0 && cursor && tl == 0) nextbuf[par] = drawn;
         // RESET BARRIER -- unconditional, in every variant of this kernel (with or without the elimination).  It orders
         //   (a) thread 0's nextbuf[par] = drawn against the readfirstlane(nextbuf[par]) of every wave below: the value is
         //       the next trajectory index and goes straight into resource(trn), an unordered read addresses memory
@@ -270,17 +323,19 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
         // Later blocks need no barrier: a wave owns every fourth pivot step, so when step s is published every wave has
         // consumed step s - 4, and a ring entry is rewritten 16 steps after its last use.
         __syncthreads();
+        SD_TICK(2);
         auto wg_barrier = [] { __syncthreads(); };
         auto no_barrier = [] {};
         (void)no_barrier; (void)wg_barrier;
         sfor<0, NR>([&](auto kbc) {
             constexpr int KB = decltype(kbc)::value;
-            if (KB == (NR > 1 ? 1 : 0)) {            // behind the RESET BARRIER (NR = 1: the value is read after the last barrier)
+            if (ks == 0 && KB == (NR > 1 ? 1 : 0)) { // behind the RESET BARRIER (NR = 1: the value is read after the last barrier)
                 if (NR > 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
             }
             if (SC_SD_XPREFETCH && NR > 1 && KB == (NR - SC_SD_XPREFETCH_AHEAD > 1 ? NR - SC_SD_XPREFETCH_AHEAD : 1)) {
-                if (trn < A.st.n) {
-                    first_requests(trn);
+                const int64_t tnext = ks + 1 < KS ? tr : trn;
+                if (tnext < A.st.n) {
+                    first_requests(tnext, std::integral_constant<int, ksn>());
                 } else {                            // nothing follows: end the live ranges of the old values
                     prv = 0.0;
 #pragma unroll
@@ -296,25 +351,50 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A) {
                 else eliminate_block<NR, KB, 64>(m, detbuf[par], D, seq0 + 1 + KB, rowbuf, pivrec, weak, tl, SC_SD_BLOCK_BARRIER);
             }
         });
+        SD_TICK(3);
         __syncthreads();
-        if (NR == 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
-        // no barrier after this: the buffers of this parity are next written two trajectories on
-        if (tl == 0 && (*weak & 1) && A.st.flags && !skip_lu) {
+        SD_TICK(4);
+        if (ks == 0 && NR == 1) trn = cursor ? (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(nextbuf[par]) : tr + gridDim.x;
+        // no barrier after this: the buffers of this parity are next written two visits on
+        cplx *c2 = (cplx *)A.st.c2;
+        // previous value / destination of this sub-step's determinant and branch sign
+        const cplx *c2_in = ks == 0 ? c2 + tr : (const cplx *)MA.c2_mid + ((int64_t)(ks - 1) * A.st.n + tr);
+        const double *sg_in = ks == 0 ? A.st.sgn + tr : MA.sgn_mid + ((int64_t)(ks - 1) * A.st.n + tr);
+        cplx *c2_out = ks == KS - 1 ? c2 + tr : (cplx *)MA.c2_mid + ((int64_t)ks * A.st.n + tr);
+        double *sg_out = ks == KS - 1 ? A.st.sgn + tr : MA.sgn_mid + ((int64_t)ks * A.st.n + tr);
+        if (ks == KS - 1 && tl == 0 && (*weak & 1) && A.st.flags && !skip_lu) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
             atomicAdd(&A.st.flags[A.st.n], 1);   // lets the fix-up launch return at once when nothing was flagged
         } else if (tl == 0) {
+            if (KS > 1 && ks < KS - 1 && (*weak & 1) && !skip_lu) atomicAdd(MA.unrepaired, 1);
             const cplx c2new = (*weak & 2) ? c_make(0.0, 0.0) : finish_determinant(detbuf[par], rows_odd);
-            cplx *c2 = (cplx *)A.st.c2;
             if (do_step) {
-                const cplx prev = c2[tr];
-                if (prev.x < 0.0 && c2new.x < 0.0 && prev.y * c2new.y < 0.0) A.st.sgn[tr] = -A.st.sgn[tr];
+                const cplx prev = *c2_in;
+                const double sg = *sg_in;
+                const bool flip = prev.x < 0.0 && c2new.x < 0.0 && prev.y * c2new.y < 0.0;
+                if (KS > 1) *sg_out = flip ? -sg : sg;
+                else if (flip) *sg_out = -sg;
             } else {
-                A.st.sgn[tr] = 1.0;
+                *sg_out = 1.0;
             }
-            c2[tr] = c2new;
+            *c2_out = c2new;
         }
+        seq0 += 4; par ^= 1;
+        SD_TICK(5);
+#ifdef SD_PHASE_CLOCK
+        ++pc_item;
+#endif
+      });
     }
 }
+
+#ifdef SD_PHASE_CLOCK
+}  // namespace
+extern "C" int sc_sd_phase_clock(unsigned long long *buf) {       // device buffer of 2*4*256*6 time stamps, or NULL to switch off
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sd_clock), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+namespace {
+#endif
 
 // "phase A" as its own launch: one wavefront per trajectory, lane = mode.  RK4 of (q_a, p_a) with the reference's
 // stage formula, the action and <T+V> at the k4 stage by wave reductions, and the 2x2 RK4 propagator P_a of the
@@ -367,6 +447,74 @@ __global__ __launch_bounds__(256) void hk_modes_kernel(StepArgs A) {
     if (threadIdx.x == 0 && A.epart) A.epart[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+
+// hk_modes_kernel for KS consecutive time steps (sc_hk_step_multi): (q_a, p_a) stay in registers between the sub-steps; row
+// propagators of sub-step ks -> work[ks][n][4][D]; (q, p, S) after sub-step ks < KS - 1 -> qp_mid / act_mid [ks][n] (what the
+// correlation kernel of time step k + ks + 1 reads), after the last one -> the state; <T+V> sums of sub-step ks -> epart[ks][grid].
+// The arithmetic of a sub-step is that of hk_modes_kernel.
+struct ModesMultiArgs {
+    double *work, *qp_mid, *act_mid;
+};
+template <int KS>
+__global__ __launch_bounds__(256) void hk_modes_multi_kernel(StepArgs A, ModesMultiArgs MM) {
+    const int D = A.st.dim, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double dt = A.dt, hh = 0.5 * dt, h6 = dt / 6.0;
+    __shared__ double wsum[KS][4];
+    double esum[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) esum[ks] = 0.0;
+    for (int64_t tr = (int64_t)blockIdx.x * 4 + wave; tr < A.st.n; tr += (int64_t)gridDim.x * 4) {
+        double *qp = A.st.qp + tr * 2 * D;
+        const bool in = lane < D;
+        double q = in ? qp[lane] : 0.0, p = in ? qp[D + lane] : 0.0;
+        const double im = in ? A.pot.inv_mass[lane] : 0.0, c0 = in ? A.pot.par0[lane] : 0.0, c1 = (in && A.pot.par1) ? A.pot.par1[lane] : 0.0;
+        double act = A.st.act[tr];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            double *pr = MM.work + ((int64_t)ks * A.st.n + tr) * 4 * (int64_t)D;
+            double red5[5] = {0, 0, 0, 0, 0};
+            if (in) {
+                double v, g, h1, h2, h3, h4;
+                sep_eval(A.pot.kind, c0, c1, q, v, g, h1);
+                const double kq1 = p * im, kp1 = -g;
+                red5[0] = 0.5 * p * p * im - v;
+                const double q2 = q + hh * kq1, p2 = p + hh * kp1;
+                sep_eval(A.pot.kind, c0, c1, q2, v, g, h2);
+                const double kq2 = p2 * im, kp2 = -g;
+                red5[1] = 0.5 * p2 * p2 * im - v;
+                const double q3 = q + hh * kq2, p3 = p + hh * kp2;
+                sep_eval(A.pot.kind, c0, c1, q3, v, g, h3);
+                const double kq3 = p3 * im, kp3 = -g;
+                red5[2] = 0.5 * p3 * p3 * im - v;
+                const double q4 = q + dt * kq3, p4 = p + dt * kp3;
+                sep_eval(A.pot.kind, c0, c1, q4, v, g, h4);
+                const double kq4 = p4 * im, kp4 = -g;
+                red5[3] = 0.5 * p4 * p4 * im - v;
+                red5[4] = 0.5 * p4 * p4 * im + v;
+                q = q + h6 * (kq1 + 2.0 * kq2 + 2.0 * kq3 + kq4);
+                p = p + h6 * (kp1 + 2.0 * kp2 + 2.0 * kp3 + kp4);
+                double u1 = 1.0, v1 = 0.0, u2 = 0.0, v2 = 1.0;
+                rk4_pair(u1, v1, im, h1, h2, h3, h4, dt);
+                rk4_pair(u2, v2, im, h1, h2, h3, h4, dt);
+                pr[lane] = u1; pr[D + lane] = u2; pr[2 * D + lane] = v1; pr[3 * D + lane] = v2;
+                double *qo = ks == KS - 1 ? qp : MM.qp_mid + ((int64_t)ks * A.st.n + tr) * 2 * D;
+                qo[lane] = q; qo[D + lane] = p;
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) red5[i] = wave_sum(red5[i]);
+            act += h6 * (red5[0] + 2.0 * red5[1] + 2.0 * red5[2] + red5[3]);
+            if (lane == 0) {
+                if (ks == KS - 1) A.st.act[tr] = act; else MM.act_mid[(int64_t)ks * A.st.n + tr] = act;
+                esum[ks] += red5[4];
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) if (lane == 0) wsum[ks][wave] = esum[ks];
+    __syncthreads();
+    if (threadIdx.x < KS && A.epart)
+        A.epart[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+}
 
 // ---- D <= 16: one WAVEFRONT per trajectory, everything in registers, no barrier and no LDS hand-off in the elimination.
 // Lane (rg, tj) = (lane >> 4, lane & 15) holds column tj of the matrix rows rg, rg + 4, rg + 8, rg + 12 (rows and
@@ -565,10 +713,10 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
 #endif
 #define SC_LAUNCH_SD(NR_, OCC_)                                                                                         \
     do {                                                                                                                \
-        if (step && tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, true>), dim3(sdgrid), dim3(256), 0, s, a);   \
-        else if (step) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, false>), dim3(sdgrid), dim3(256), 0, s, a);     \
-        else if (tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, true>), dim3(sdgrid), dim3(256), 0, s, a);    \
-        else hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, false>), dim3(sdgrid), dim3(256), 0, s, a);              \
+        if (step && tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, true>), dim3(sdgrid), dim3(256), 0, s, a, MultiArgs{});   \
+        else if (step) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, true, false>), dim3(sdgrid), dim3(256), 0, s, a, MultiArgs{});     \
+        else if (tiled) hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, true>), dim3(sdgrid), dim3(256), 0, s, a, MultiArgs{});    \
+        else hipLaunchKernelGGL((hk_step_sd_kernel<NR_, OCC_, false, false>), dim3(sdgrid), dim3(256), 0, s, a, MultiArgs{});              \
     } while (0)
     switch (nr) {
         case 1: SC_LAUNCH_SD(1, 4); break;
@@ -585,4 +733,22 @@ int sc_launch_step_sd(const StepArgs &a, hipStream_t s) {
     }
 #undef SC_LAUNCH_SD
     return sc_check_launch("sc_hk_step (separable/diagonal fast path)");
+}
+
+// TWO time steps per visit (sc_hk_step_multi; the caller has validated: separable potential, diagonal widths, 16 < D <= 64, tiled
+// blocks, flags present): hk_modes_multi_kernel<2>, then the block kernel with two sub-steps per trajectory.
+int sc_launch_step_sd_multi(const StepArgs &a, const sc_multi_scratch &ms, hipStream_t s) {
+    const int D = a.st.dim, nr = (D + 15) / 16, grid = sc_step_grid(a.st.n, D);
+    ModesMultiArgs mm{ms.work, ms.qp_mid, ms.act_mid};
+    hipLaunchKernelGGL(hk_modes_multi_kernel<2>, dim3(grid), dim3(256), 0, s, a, mm);
+    int rc = sc_check_launch("sc_hk_step_multi (modes)");
+    if (rc) return rc;
+    MultiArgs ma{ms.work, ms.c2_mid, ms.sgn_mid, ms.unrepaired};
+    switch (nr) {
+        case 2: hipLaunchKernelGGL((hk_step_sd_kernel<2, 4, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break;
+        case 3: hipLaunchKernelGGL((hk_step_sd_kernel<3, 4, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break;
+        case 4: hipLaunchKernelGGL((hk_step_sd_kernel<4, 4, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break;
+        default: return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_step_multi: D = %d", D);
+    }
+    return sc_check_launch("sc_hk_step_multi (two steps per visit)");
 }

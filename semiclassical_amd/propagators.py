@@ -24,7 +24,7 @@ import torch
 
 from . import _lib, hostmath
 from ._lib import (lib, check, ptr, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts,
-                   sc_dense_scratch)
+                   sc_dense_scratch, sc_multi_scratch)
 from .units import hbar
 
 __all__ = ['HermanKlukPropagator', 'WaltonManolopoulosPropagator']
@@ -219,6 +219,11 @@ class HermanKlukPropagator(object):
         self._mdiag[:, 0] = 1.0
         self._mdiag[:, 3] = 1.0
         self._mono_is_diag, self._mono_stale = True, False
+        # The monodromy blocks are the identity now and stay DIAGONAL as long as only separable potentials act on them.  Nothing in
+        # the dense-state kernels uses that -- except that diagonal blocks cannot meet a weak pivot, which is what lets run() take
+        # two time steps per visit (sc_hk_step_multi: an intermediate determinant cannot be repaired after the fact).
+        self._blocks_structurally_diagonal = True
+        self._multi = None
 
         self._prepare()
         self.t = 0.0
@@ -298,17 +303,21 @@ class HermanKlukPropagator(object):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if hasattr(potential, "_gdml_model"):
+            self._blocks_structurally_diagonal = False
             self._sync_dense_mono(leave_diagonal=True)
             self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
             nblocks = self._launch_dense_step(potential, dt, s)
         elif not hasattr(potential, "_descriptor") or self.dim > 64:
             # no device descriptor, or beyond the fused kernels' D <= 64: the potential's own torch code + dense path
+            self._blocks_structurally_diagonal = False
             self._sync_dense_mono(leave_diagonal=True)
             self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
             nblocks = self._launch_generic_step(potential, dt, s)
         else:
             if desc is None:
                 desc = self._potential_descriptor(potential, dt)
+            if desc.kind not in (_lib.SC_POT_MORSE, _lib.SC_POT_HARMONIC_SEP, _lib.SC_POT_EPS_MORSE):
+                self._blocks_structurally_diagonal = False          # a dense Hessian couples the rows
             if self._shortcut_applies(desc):
                 check(lib.sc_hk_step_diag(desc, self._state, self._hk, ptr(self._mdiag), dt, 0, ptr(self._epart), s))
                 self._mono_stale = True
@@ -320,7 +329,7 @@ class HermanKlukPropagator(object):
             nblocks = self._gstep
         if timed:
             e1.record()
-            self.__dict__.setdefault("_step_events", []).append((e0, e1))
+            self.__dict__.setdefault("_step_events", []).append((e0, e1, 1))
         check(lib.sc_energy_guard(ptr(self._epart), nblocks, float(self.ntraj), ptr(self._elog), s))
         self._nsteps += 1
         if not remembered:
@@ -441,6 +450,9 @@ class HermanKlukPropagator(object):
     def synchronize(self):
         torch.cuda.current_stream(self.device).synchronize()
         self._run_scratch = None              # partial sums of the last whole-loop run(): consumed by now
+        if self._multi is not None and int(self._multi["bad"].item()) != 0:
+            raise _lib.EngineError("sc_hk_step_multi met a weak pivot in an intermediate determinant although the monodromy blocks "
+                                   "were taken to be diagonal: the results of this run() are not reliable")
         self._check_energy_guard()
 
     def mean_energy(self):
@@ -449,9 +461,10 @@ class HermanKlukPropagator(object):
         return float(self._elog[1].item())
 
     def step_kernel_times_ms(self):
-        """durations of the step-kernel launches recorded while ``profile_step_kernel`` was set"""
+        """duration PER TIME STEP of the step-kernel launches recorded while ``profile_step_kernel`` was set (a launch of the
+        two-steps-per-visit path counts for two)"""
         torch.cuda.current_stream(self.device).synchronize()
-        return [e0.elapsed_time(e1) for e0, e1 in self.__dict__.get("_step_events", [])]
+        return [e0.elapsed_time(e1) / steps for e0, e1, steps in self.__dict__.get("_step_events", [])]
 
     # ------------------------------------------------------------------ correlation functions
     def _nac_is_current(self, potential):
@@ -522,15 +535,16 @@ class HermanKlukPropagator(object):
         else:
             check(lib.sc_reduce_slot_at(ptr(partials), count, C_void(slot_ptr), ptr(cursor), self._stream()))
 
-    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None, slot_row=None):
+    def _launch_correlate(self, slot_ptr, per_trajectory=True, cursor=None, slot_row=None, state=None):
         """per-trajectory terms + their sums for the current state into the 5-double slot at `slot_ptr` (`slot_row`: the same
-        five doubles as a tensor, needed when the k_ic sum is formed by torch: position-dependent couplings)"""
+        five doubles as a tensor, needed when the k_ic sum is formed by torch: position-dependent couplings; `state`: another
+        view of (q, p, S, c2, sign) -- the state between the two steps of sc_hk_step_multi)"""
         s = self._stream()
         nac = self._nac
         generic = getattr(self, "_nac_generic", None) is not None
         per_trajectory = per_trajectory or generic
         with self._timed("hk_correlate"):
-            check(lib.sc_hk_correlate(self._state, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
+            check(lib.sc_hk_correlate(self._state if state is None else state, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
                                       ptr(self._nacq) if nac is not None else None, self._mc_norm(),
                                       ptr(self._cq) if per_trajectory else None,
                                       ptr(self._kq) if per_trajectory else None, ptr(self._cpart), s))
@@ -598,10 +612,22 @@ class HermanKlukPropagator(object):
         elif use_graph and fused and nt > 2 and not getattr(self, "profile_step_kernel", False) and not self.kernel_timing:
             self._run_graph(potential, dt, nt, desc, slots)
         else:
-            for k in range(nt):
+            pairs = fused and nt >= 2 and self._multi_applies(desc)
+            k = 0
+            while k < nt:
                 self._launch_correlate(base + 40 * k, per_trajectory=False, slot_row=slots[k])
-                self._launch_step(potential, dt, desc=desc, remembered=True)
-                self.t += dt
+                if pairs and k + 1 < nt:
+                    # TWO time steps per visit of a trajectory (sc_hk_step_multi): the second step's loads of the monodromy blocks
+                    # hit the memory-side cache instead of HBM; its correlation terms come from the state between the two steps
+                    self._launch_step_pair(desc, dt)
+                    self._launch_correlate(base + 40 * (k + 1), per_trajectory=False, state=self._multi["state_mid"])
+                    self.t += dt
+                    self.t += dt
+                    k += 2
+                else:
+                    self._launch_step(potential, dt, desc=desc, remembered=True)
+                    self.t += dt
+                    k += 1
         self._corr_step = -1
         if not own:
             return None
@@ -616,6 +642,8 @@ class HermanKlukPropagator(object):
                 and bool(lib.sc_hk_run_supported(desc, self._hk, self._ovl_t0)))
 
     def _run_whole_loop(self, desc, dt, nt, slots):
+        if desc.kind not in (_lib.SC_POT_MORSE, _lib.SC_POT_HARMONIC_SEP, _lib.SC_POT_EPS_MORSE):
+            self._blocks_structurally_diagonal = False
         self._sync_dense_mono(leave_diagonal=True)
         self._set_mono_layout(_lib.SC_MONO_ROWMAJOR)
         nslots = lib.sc_hk_run_slots(self.ntraj, self.dim)
@@ -634,6 +662,51 @@ class HermanKlukPropagator(object):
         self._nsteps += nt
         for _ in range(nt):
             self.t += dt                      # accumulated as the reference's loop does (propagators.py:655)
+
+    _multi_ok = True                # WM needs its own kernel after every single step
+    pair_steps = True               # run(): two time steps per visit where sc_hk_step_multi applies (False: one launch per step)
+
+    def _multi_applies(self, desc):
+        """two time steps per visit (sc_hk_step_multi): separable potential, diagonal widths, 16 < D <= 64 (the tiled fast path),
+        and blocks that are still diagonal -- an intermediate determinant with a weak pivot could not be repaired"""
+        if not (self._multi_ok and self.pair_steps and self._blocks_structurally_diagonal and self._nac_generic is None
+                and not self._shortcut_applies(desc) and self._fast_path_layout(desc) == _lib.SC_MONO_TILED16):
+            return False
+        probe = sc_state.from_buffer_copy(self._state)
+        probe.mono_layout = _lib.SC_MONO_TILED16
+        return bool(lib.sc_hk_step_multi_supported(desc, probe, self._hk))
+
+    def _launch_step_pair(self, desc, dt):
+        n, d, dev = self.ntraj, self.dim, self.device
+        if self._multi is None:
+            grid = self._gstep
+            bufs = {"work": torch.empty((2, n, 4, d), dtype=F64, device=dev), "qp": torch.empty((n, 2 * d), dtype=F64, device=dev),
+                    "act": torch.empty(n, dtype=F64, device=dev), "c2": torch.empty(n, dtype=C128, device=dev),
+                    "sgn": torch.empty(n, dtype=F64, device=dev), "bad": torch.zeros(1, dtype=torch.int32, device=dev),
+                    "epart": torch.zeros((2, grid), dtype=F64, device=dev)}
+            bufs["ms"] = sc_multi_scratch(work=ptr(bufs["work"]), qp_mid=ptr(bufs["qp"]), act_mid=ptr(bufs["act"]), c2_mid=ptr(bufs["c2"]),
+                                          sgn_mid=ptr(bufs["sgn"]), unrepaired=ptr(bufs["bad"]))
+            mid = sc_state.from_buffer_copy(self._state)
+            mid.qp, mid.act, mid.c2, mid.sgn = ptr(bufs["qp"]), ptr(bufs["act"]), ptr(bufs["c2"]), ptr(bufs["sgn"])
+            bufs["state_mid"] = mid
+            self._multi = bufs
+        m = self._multi
+        s = self._stream()
+        self._sync_dense_mono(leave_diagonal=True)
+        self._set_mono_layout(_lib.SC_MONO_TILED16)
+        m["state_mid"].mono_layout = _lib.SC_MONO_TILED16
+        timed = getattr(self, "profile_step_kernel", False)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        with self._timed("hk_step_pair"):
+            check(lib.sc_hk_step_multi(desc, self._state, self._hk, m["ms"], dt, ptr(m["epart"]), s))
+        if timed:
+            e1.record()
+            self.__dict__.setdefault("_step_events", []).append((e0, e1, 2))
+        for sub in range(2):
+            check(lib.sc_energy_guard(C_void(m["epart"].data_ptr() + 8 * sub * self._gstep), self._gstep, float(n), ptr(self._elog), s))
+        self._nsteps += 2
 
     def _run_graph(self, potential, dt, nt, desc, slots):
         """first iteration eagerly (lazy set-up, layout conversion), then one captured iteration replayed nt - 1 times"""
@@ -700,6 +773,7 @@ class HermanKlukPropagator(object):
         diag = torch.diagonal(self._mono, dim1=2, dim2=3)
         self._mono_stale = False
         self._mono_is_diag = bool(torch.count_nonzero(self._mono) == torch.count_nonzero(diag))
+        self._blocks_structurally_diagonal = self._mono_is_diag
         if self._mono_is_diag:
             self._mdiag.copy_(diag)
 
@@ -885,6 +959,7 @@ class WaltonManolopoulosPropagator(HermanKlukPropagator):
 
     _tiled_fast_path = False        # the Filinov matrix is built from the row-major blocks after every step
     _whole_loop_ok = False          # ... by its own kernel, between the steps
+    _multi_ok = False
 
     def __init__(self, Gamma_i, Gamma_t, alpha, beta, device='cuda'):
         super().__init__(Gamma_i, Gamma_t, device=device)      # the Filinov matrix needs the dense monodromy blocks

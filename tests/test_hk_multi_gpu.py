@@ -1,0 +1,155 @@
+"""Two time steps per visit of a trajectory (sc_hk_step_multi, include/semiclassical_hip.h): the same arithmetic as two
+sc_hk_step launches -- reference propagators.py:342-357 (RK4 step) and 624-716 (prefactor) applied twice -- with the second
+step's loads served by the cache.  The bar is therefore bit-identity with the step-at-a-time path, not a tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(D, n, seed=0):
+    import bench
+    from semiclassical_amd import potentials as P, propagators as PR
+    torch.set_default_dtype(torch.float64)
+    omega, chi, nac, q0, _ = bench.as60_model(D)
+    G = torch.diag(omega)
+    props = []
+    for _ in range(2):
+        prop = PR.HermanKlukPropagator(G, G, device="cuda")
+        prop.initial_conditions(q0, 0.0 * q0, G, ntraj=n, generator=torch.Generator().manual_seed(seed + D))
+        props.append(prop)
+    return props, P.MorsePotential(omega, chi.clone(), nac), float(0.5 * omega.sum())
+
+
+def _same_state(a, b):
+    assert a._state.mono_layout == b._state.mono_layout
+    for x, y in ((a._qp, b._qp), (a._act, b._act), (a._mono, b._mono), (a._sgn, b._sgn)):
+        assert torch.equal(x, y)
+    assert torch.equal(torch.view_as_real(a._c2), torch.view_as_real(b._c2))
+
+
+@pytest.mark.parametrize("D,n,nt", [(60, 2500, 5), (33, 700, 4), (17, 130, 3), (48, 1100, 2), (49, 90, 6), (64, 300, 5), (32, 1, 4)])
+def test_two_steps_per_visit_equal_single_steps(D, n, nt):
+    """run() in pairs (+ a single step when nt is odd) against nt launches of the one-step kernel: state, determinants, signs
+    and both correlation functions bit for bit; more trajectories than persistent workgroups included (cursor hand-out)"""
+    (a, b), pot, E0 = _pair(D, n)
+    dt = 4.0
+    ca, ka = a.run(pot, dt, nt, E0)
+    assert a._multi is not None, "the pair path was not taken"
+    cb, kb = np.zeros(nt, dtype=complex), np.zeros(nt, dtype=complex)
+    for k in range(nt):
+        c, kk = b.run(pot, dt, 1, E0)                    # nt = 1: no pair to form
+        cb[k], kb[k] = c[0], kk[0]
+    assert b._multi is None
+    a.synchronize()
+    _same_state(a, b)
+    assert a.t == b.t and a._nsteps == b._nsteps == nt
+    # run() multiplies by the phase of the running time, which is accumulated identically
+    assert np.array_equal(ca, cb) and np.array_equal(ka, kb)
+    assert int(a._multi["bad"].item()) == 0
+
+
+def test_pairs_against_the_oracle():
+    """the pair path against the CPU oracle (not only against the engine's own one-step kernel)"""
+    import bench
+    from oracle import sc_oracle as orc
+    D, n, nt, dt = 60, 24, 6, 4.0
+    (a, _), pot, E0 = _pair(D, n, seed=7)
+    omega, chi, nac, q0, _ = bench.as60_model(D)
+    G = torch.diag(omega)
+    ref = orc.HKOracle(G, G)
+    ref.set_initial_conditions(q0, 0.0 * q0, G, a.zi.cpu(), a.probi.cpu())
+    rc, rk = orc.run_loop(ref, orc.MorseOracle(omega, chi.clone(), nac), dt, nt, E0)
+    c, k = a.run(pot, dt, nt, E0)
+    assert a._multi is not None
+    assert cases.rel_err(c, rc) < 1e-9 and cases.rel_err(k, rk) < 1e-9
+    assert cases.rel_err(a.y.cpu().numpy(), ref.y.numpy()) < 1e-10
+    assert cases.rel_err(a._c2.cpu().numpy(), ref.c2.numpy()) < 1e-9
+
+
+def test_golden_as60_through_pairs():
+    """the reference's golden C(t), k_ic(t) of the 60-mode model through the pair path"""
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load("hk_as60")
+    pot, prop = engine_potential(g), engine_propagator(g)
+    c, k = prop.run(pot, float(g["dt"]), int(g["nt"]), float(g["E0"]))
+    assert prop._multi is not None
+    assert cases.rel_err(c, g["cauto"]) < 1e-9 and cases.rel_err(k, g["kic"]) < 1e-9
+
+
+def test_pairs_are_not_formed_for_dense_blocks_or_other_kernels():
+    """an intermediate determinant cannot be repaired after the fact, so run() pairs steps only while the blocks are known to be
+    diagonal; a state handed in through `y` with dense blocks, WM, D <= 16 and the diagonal shortcut keep their paths"""
+    from semiclassical_amd import propagators as PR
+    (a, b), pot, E0 = _pair(33, 40)
+    y = a.y.clone()
+    D = 33
+    y[2 * D:2 * D + 4 * D * D] += 0.1 * torch.randn((4 * D * D, 40), generator=torch.Generator().manual_seed(1)).cuda()
+    a.y = y
+    b.y = y
+    ca, ka = a.run(pot, 4.0, 4, E0)
+    assert a._multi is None and not a._blocks_structurally_diagonal
+    cb = [b.run(pot, 4.0, 1, E0)[0][0] for _ in range(4)]
+    assert np.array_equal(ca, np.array(cb))
+    # diagonal blocks handed in through `y` are recognised
+    (c, _), pot, E0 = _pair(33, 40)
+    c.y = c.y.clone()
+    c.run(pot, 4.0, 2, E0)
+    assert c._multi is not None
+    (d16, _), pot16, E16 = _pair(16, 40)
+    d16.run(pot16, 4.0, 4, E16)
+    assert d16._multi is None
+    import bench
+    omega, chi, nac, q0, _ = bench.as60_model(33)
+    G = torch.diag(omega)
+    short = PR.HermanKlukPropagator(G, G, device="cuda", exploit_separability=True)
+    short.initial_conditions(q0, 0.0 * q0, G, ntraj=16)
+    short.run(pot, 4.0, 4, E0)
+    assert short._multi is None
+    assert PR.WaltonManolopoulosPropagator._multi_ok is False
+
+
+def test_weak_pivot_in_an_intermediate_determinant_is_counted_and_raised():
+    """sc_hk_step_multi called (through the C-ABI, against run()'s rule) on cyclically shifted blocks: every leading pivot of the
+    register elimination is zero.  The last sub-step is repaired as in sc_hk_step (determinants equal to the one-step path),
+    the intermediate one cannot be: the call counts the trajectories in sc_multi_scratch.unrepaired and synchronize() raises."""
+    from semiclassical_amd import _lib
+    D, n = 33, 50
+    (a, b), pot, E0 = _pair(D, n)
+    y = a.y.clone()
+    gen = torch.Generator().manual_seed(3)
+    shift = torch.roll(torch.eye(D), 11, dims=1).unsqueeze(2).expand(-1, -1, n).clone() * (1.0 + 0.1 * torch.rand(D, D, n, generator=gen))
+    zero = torch.zeros(D, D, n)
+    for k, blk in enumerate([shift, zero, zero, shift.clone()]):
+        y[2 * D + k * D * D: 2 * D + (k + 1) * D * D] = blk.reshape(D * D, n).cuda()
+    a.y = y
+    b.y = y
+    desc = a._potential_descriptor(pot, 4.0)
+    a._launch_step_pair(desc, 4.0)
+    b.step(pot, 4.0)
+    b.step(pot, 4.0)
+    torch.cuda.synchronize()
+    assert int(a._multi["bad"].item()) == n
+    b._set_mono_layout(_lib.SC_MONO_TILED16)
+    _same_state(a, b)                                  # the FINAL determinants went through the fix-up launch
+    with pytest.raises(_lib.EngineError, match="weak pivot"):
+        a.synchronize()
+
+
+def test_multi_supported_reports_the_shapes():
+    from semiclassical_amd import _lib
+    from semiclassical_amd._lib import lib
+    for D, want in ((17, 1), (33, 1), (60, 1), (64, 1), (16, 0), (5, 0)):
+        (a, _), pot, _ = _pair(D, 8)
+        desc = a._potential_descriptor(pot, 4.0)
+        st = type(a._state).from_buffer_copy(a._state)
+        st.mono_layout = _lib.SC_MONO_TILED16
+        assert lib.sc_hk_step_multi_supported(desc, st, a._hk) == want
+        st.mono_layout = _lib.SC_MONO_ROWMAJOR
+        assert lib.sc_hk_step_multi_supported(desc, st, a._hk) == 0
+        st.mono_layout = _lib.SC_MONO_TILED16
+        st.flags = None
+        assert lib.sc_hk_step_multi_supported(desc, st, a._hk) == 0

@@ -53,3 +53,9 @@ for occ in os.environ.get("OCC_LIST", "2").split(","):
     what = "WITHOUT elimination" if os.environ.get("SC_DEBUG_SKIP_LU") else "full"
     print(f"D={DIM} n={n} occ={occ} [{what}]: step {t_full:.3f} ms ({ab / t_full / 1e6:.0f} GB/s algorithmic) | "
           f"prefactor-only launch (no RK4 / stores) {t_pref:.3f} ms", flush=True)
+if prop._state.mono_layout == 1 and lib.sc_hk_step_multi_supported(desc, prop._state, prop._hk):
+    prop._launch_step_pair(desc, dt)              # allocates the scratch of sc_hk_step_multi
+    m = prop._multi
+    pair = lambda: check(lib.sc_hk_step_multi(desc, prop._state, prop._hk, m["ms"], dt, ptr(m["epart"]), prop._stream()))
+    t_pair = timed(pair)
+    print(f"D={DIM} n={n} two steps per visit [{what}]: {t_pair / 2:.3f} ms per step ({t_pair:.3f} per launch)", flush=True)

@@ -22,6 +22,6 @@ B="SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 rocprofv3 --kernel-trace --pmc $A -d $out/pmcA_bench -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmcA_bench.log 2>&1
 rocprofv3 --kernel-trace --pmc $B -d $out/pmcB_bench -o run -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-configs > $out/pmcB_bench.log 2>&1
 python tools/pmc_summary.py $dst/${tag}_bench_pmc.json "headline configuration (60-mode AS, n = 1e5, HK): SQ counters of the step, modes and correlation kernels, two rocprofv3 --pmc passes" \
-    hk_step_sd_kernel,hk_modes_kernel,hk_correlate_kernel $out/pmcA_bench $out/pmcB_bench > /dev/null
+    hk_step_sd_kernel,hk_modes_kernel,hk_modes_multi_kernel,hk_correlate_kernel $out/pmcA_bench $out/pmcB_bench > /dev/null
 echo "headline done"
 tools/profile_configs.sh $tag
