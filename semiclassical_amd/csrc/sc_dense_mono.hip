@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
     constexpr int RW = 16 * NR;
     __shared__ cplx rowbuf[16][RW];
     __shared__ PivotRecord pivrec[16];
-    __shared__ cplx detbuf[16];
+    __shared__ cplx detbuf[16 * NR];
     __shared__ int weak;                     // bit 0: weak in-block pivot, bit 1: zero pivot
     __shared__ double scl[4 * RW];           // st, 1/st, si, 1/si
     const int D = A.st.dim, DD = D * D, tid = threadIdx.x, tj = tid & 15;
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
     for (int64_t tr = blockIdx.x; tr < A.st.n; tr += gridDim.x, seq0 += NR) {
         const double *M = A.st.mono + tr * 4 * (int64_t)DD;
         if (tid == 0) weak = 0;
-        if (tid < 16) detbuf[tid] = c_make(1.0, 0.0);
+        if (tid < 16 * NR) detbuf[tid] = c_make(1.0, 0.0);
         int til = trow, tjl = tj;
         __asm__ volatile("" : "+v"(til), "+v"(tjl));            // LDS indices recomputed per trajectory, not hoisted and spilled
         cplx m[NR][NR];
@@ -695,6 +695,7 @@ __global__ __launch_bounds__(256, NR > 4 ? 2 : 4) void dense_prefactor_reg_kerne
         }
         eliminate_all_blocks<NR, 0, RW>(m, detbuf, D, seq0, rowbuf, pivrec, &weak, tid, barrier);
         __syncthreads();
+        if (tid < 16) lu_partial_products<NR>(detbuf, tid);
         if (tid == 0) {
             if (weak) {
                 A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted LDS elimination

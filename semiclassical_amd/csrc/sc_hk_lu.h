@@ -130,10 +130,10 @@ __device__ __forceinline__ void column_fetch(const cplx (&m)[NR][NR], cplx (&c)[
 // The 16 lanes that own row k = 16*KB + kt pick the pivot column among the live columns of the diagonal block,
 // scale the row by 1/pivot and publish it: row -> rowbuf[kt], pivot -> pivrec[kt], and LAST the record's tag
 // (= seq), which the consumers poll.  LDS operations of one wave execute in issue order, so a consumer that sees
-// the tag sees the row.  Runs inside `if (ti == kt)`.  The winner lane multiplies the (signed) pivot into detbuf[row
-// group] in LDS -- every row group accumulates the pivots of its own rows, one thread multiplies the 16 partial products
-// at the end -- and a zero pivot sets bit 1 of *weak: no thread carries the determinant or a singularity flag in
-// registers.  detbuf[0..16) must hold 1 before the first block starts.
+// the tag sees the row.  Runs inside `if (ti == kt)`.  The winner lane stores the (signed) pivot to detbuf[16 KB + kt] in
+// LDS (a plain store: round 4; it used to multiply it into a per-row-group product, a read-modify-write on the owner's
+// path) -- lu_partial_products / finish_determinant multiply them at the end -- and a zero pivot sets bit 1 of *weak: no
+// thread carries the determinant or a singularity flag in registers.  detbuf[0..16 NR) must hold 1 before the first block.
 template <int NR, int KB, int RW>
 __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx *detbuf, bool live, int kt, int seq,
                                                   cplx (*rowbuf)[RW], PivotRecord *pivrec, int *weak, int tid) {
@@ -151,16 +151,16 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
     // 16 owner lanes are active, so the ballot holds exactly their `live` bits) = p adjacent transpositions
     const unsigned long long lm = __ballot(live);
     const int flip = (__popcll(lm & ((1ull << src) - 1ull)) & 1) << 31;
-    const bool keep = live && tj != pl;
-    const cplx r0 = c_mul(m[KB][KB], inv);
-    rowbuf[kt][16 * KB + tj] = c_make(keep ? r0.x : 0.0, keep ? r0.y : 0.0);
+    // no masking of the columns that are not live: their entries in this row are exactly zero already (a pivot column is
+    // cleared in every remaining row by its own step: a - a * 1), and the pivot column itself gets r = 1, which clears it
+    rowbuf[kt][16 * KB + tj] = c_mul(m[KB][KB], inv);
 #pragma unroll
     for (int rb = KB + 1; rb < NR; ++rb) rowbuf[kt][16 * rb + tj] = c_mul(m[KB][rb], inv);
     if (tj == pl) {                                       // the winner publishes the pivot itself
         if (m[KB][KB].x == 0.0 && m[KB][KB].y == 0.0) atomicOr(weak, 2);      // singular: det = 0
         const cplx piv = c_make(__hiloint2double(__double2hiint(m[KB][KB].x) ^ flip, __double2loint(m[KB][KB].x)),
                                 __hiloint2double(__double2hiint(m[KB][KB].y) ^ flip, __double2loint(m[KB][KB].y)));
-        detbuf[tid >> 4] = c_mul(detbuf[tid >> 4], piv);
+        detbuf[16 * KB + kt] = piv;
         __asm__ volatile("" ::: "memory");
         __hip_atomic_store(&pivrec[kt].pad, (seq << 4) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -193,7 +193,7 @@ __device__ __forceinline__ bool pivot_step_valid(int kt, int nk) { return 4 * (k
 
 // `tid` = index of the thread inside its 256-thread elimination group (= threadIdx.x when the group is the workgroup),
 // `barrier()` synchronises the four wavefronts of the group.
-// `detbuf`: the 16 partial products of pivots in LDS (see publish_pivot_row), all 1 before block 0.
+// `detbuf`: the 16 NR signed pivots in LDS (see publish_pivot_row), all 1 before block 0.
 template <int NR, int KB, int RW, class Barrier>
 __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx *detbuf, int D, int seq,
                                                 cplx (*rowbuf)[RW], PivotRecord *pivrec, int *weak, int tid,
@@ -233,9 +233,20 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx *detbuf,
     }
 }
 
-// The product of the 16 row groups' partial (signed) pivot products times the sign of the ROW order (one thread, after
-// the barrier that ends the elimination).  The signs of the column choices are in the partial products already.
+// The determinant from the signed pivots in detbuf[16 * KB + kt] (slots of skipped steps hold 1), after the barrier that ends the
+// elimination: threads 0..15 (one wavefront: LDS operations of a wave execute in order) multiply the NR pivots of their step index
+// into detbuf[0..16), thread 0 multiplies those 16 and applies the sign of the ROW order.  The signs of the column choices are in
+// the pivots already.  Call lu_partial_products from the first 16 threads, then finish_determinant from thread 0.
+template <int NR>
+__device__ __forceinline__ void lu_partial_products(cplx *detbuf, int t) {
+    cplx p = detbuf[t];
+#pragma unroll
+    for (int kb = 1; kb < NR; ++kb) p = c_mul(p, detbuf[16 * kb + t]);
+    detbuf[t] = p;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
 __device__ __forceinline__ cplx finish_determinant(const cplx *detbuf, bool rows_odd) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     cplx det = detbuf[0];
 #pragma unroll
     for (int g = 1; g < 16; ++g) det = c_mul(det, detbuf[g]);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
     __shared__ PivotRecord pivrec[16];
     // per-trajectory results of the elimination, double-buffered by trajectory parity: thread 0 finishes trajectory t
     // (product of the partial determinants, branch tracker) while the other waves already stream trajectory t+1
-    __shared__ cplx detbuf[2][16];           // signed partial pivot products of the 16 row groups
+    __shared__ cplx detbuf[2][16 * NR];      // signed pivots, slot 16 KB + kt
     __shared__ int weakbuf[2];               // bit 0: weak in-block pivot (-> pivoted fallback), bit 1: zero pivot
     __shared__ int nextbuf[2];               // what thread 0 drew from the trajectory cursor
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
         const int tj = tl & 15, tjl = tj;
         const int til = (tl >> 6) * 4 + ((tl >> 4) & 3);    // wave w holds rows 4w .. 4w+3 of every 16-row slot
         if (tl == 0) *weak = SC_SD_FORCE_FIXUP;             // 1: variant library that hands every trajectory to the fallback
-        if (tl < 16) detbuf[par][tl] = c_make(1.0, 0.0);
+        if (tl < 16 * NR) detbuf[par][tl] = c_make(1.0, 0.0);
         int drawn = 0;
         if (ks == 0 && cursor && tl == 0) drawn = atomicAdd(cursor, 1);
         const int pk = tl >> 6, pa = tl & 63;               // thread -> (row of P, mode) of st.work
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
         const double *sg_in = ks == 0 ? A.st.sgn + tr : MA.sgn_mid + ((int64_t)(ks - 1) * A.st.n + tr);
         cplx *c2_out = ks == KS - 1 ? c2 + tr : (cplx *)MA.c2_mid + ((int64_t)ks * A.st.n + tr);
         double *sg_out = ks == KS - 1 ? A.st.sgn + tr : MA.sgn_mid + ((int64_t)ks * A.st.n + tr);
+        if (tl < 16) lu_partial_products<NR>(detbuf[par], tl);
         if (ks == KS - 1 && tl == 0 && (*weak & 1) && A.st.flags && !skip_lu) {
             A.st.flags[tr] = 1;                  // c2 / sgn are left to the fully pivoted fallback
             atomicAdd(&A.st.flags[A.st.n], 1);   // lets the fix-up launch return at once when nothing was flagged
