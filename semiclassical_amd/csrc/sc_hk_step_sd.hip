@@ -44,6 +44,9 @@
 #ifndef SC_SD_XPREFETCH
 #define SC_SD_XPREFETCH 1  // request row slot 0 of the next trajectory before the last diagonal block of the elimination
 #endif
+#ifndef SC_SD_XPREFETCH2
+#define SC_SD_XPREFETCH2 1 // also row slot 1 of the next trajectory (both raw buffers are free during the last diagonal block): -3 %
+#endif
 #ifndef SC_SD_XPREFETCH_AHEAD
 #define SC_SD_XPREFETCH_AHEAD 1   // diagonal blocks of the elimination that run after the next trajectory's first requests
 #endif
@@ -248,9 +251,12 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
         };
         auto first_requests = [&](int64_t t, auto ksnc) {    // P_a and row slot 0 of sub-step ksnc of trajectory t
             constexpr int k2 = decltype(ksnc)::value;
+            constexpr int aux2 = k2 == 0 ? (KS > 1 ? SC_SD_MULTI_LOAD_AUX : SC_SD_LOAD_AUX) : SC_SD_MULTI_MID_AUX;
             const double *wk = KS > 1 ? MA.work + (int64_t)k2 * A.st.n * 4 * Dl : A.st.work;
             if (!SC_SD_DIRECT_P && do_step && pa < Dl) prv = wk[(t * 4 + pk) * (int64_t)Dl + pa];
-            load_slot(std::integral_constant<int, 0>(), t, std::integral_constant<int, (k2 == 0 ? (KS > 1 ? SC_SD_MULTI_LOAD_AUX : SC_SD_LOAD_AUX) : SC_SD_MULTI_MID_AUX)>());
+            load_slot(std::integral_constant<int, 0>(), t, std::integral_constant<int, aux2>());
+            // SC_SD_XPREFETCH2: row slot 1 as well (both raw buffers are free during the last diagonal block)
+            if (SC_SD_XPREFETCH2 && NR > 1) load_slot(std::integral_constant<int, (NR > 1 ? 1 : 0)>(), t, std::integral_constant<int, aux2>());
         };
         auto finish_slot = [&](auto rac) {
             constexpr int ra = decltype(rac)::value;
@@ -301,7 +307,9 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
         }
         sfor<0, NR>([&](auto rac) {
             constexpr int ra = decltype(rac)::value;
-            if (SC_SD_DEPTH == 1 && ra > 0) load_slot(rac, tr, std::integral_constant<int, aux_load>());
+            // SC_SD_XPREFETCH2: slots 0 and 1 were requested during the previous elimination (requesting slot 2 before slot 1 is
+            // finished as well: 4 spilled registers, 0.5 % slower)
+            if (SC_SD_DEPTH == 1 && ra > (SC_SD_XPREFETCH2 ? 1 : 0)) load_slot(rac, tr, std::integral_constant<int, aux_load>());
             if (SC_SD_DEPTH > 1 && ra + 1 < NR && ra > 0) load_slot(std::integral_constant<int, (ra + 1 < NR ? ra + 1 : 0)>(), tr, std::integral_constant<int, aux_load>());
             __builtin_amdgcn_sched_barrier(0);
             finish_slot(rac);
@@ -342,7 +350,10 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
                     for (int pl = 0; pl < 4; ++pl) {
                         pv[0][pl] = 0.0;
 #pragma unroll
-                        for (int rb = 0; rb < NR; ++rb) raw[0][pl][rb] = 0.0;
+                        for (int rb = 0; rb < NR; ++rb) {
+                            raw[0][pl][rb] = 0.0;
+                            if (SC_SD_XPREFETCH2) raw[1][pl][rb] = 0.0;
+                        }
                     }
                 }
             }
