@@ -199,14 +199,17 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx *detbuf,
                                                 cplx (*rowbuf)[RW], PivotRecord *pivrec, int *weak, int tid,
                                                 Barrier &&barrier) {
     const int ti = ((tid >> 4) & 3) * 4 + (tid >> 6), tj = tid & 15;
-    const int nk = min(16, D - 16 * KB);
-    bool live = 16 * KB + tj < D;
+    // every caller instantiates NR = ceil(D / 16): only the LAST diagonal block can be partial, the others run their 16 steps
+    // without the (scalar, but serial) search for the next valid step
+    constexpr bool FULL = KB + 1 < NR;
+    const int nk = FULL ? 16 : min(16, D - 16 * KB);
+    bool live = FULL ? true : 16 * KB + tj < D;
     barrier();
     if (ti == 0) publish_pivot_row<NR, KB, RW>(m, detbuf, live, 0, seq, rowbuf, pivrec, weak, tid);
     for (int kt = 0; kt < 16; ++kt) {
-        if (!pivot_step_valid(kt, nk)) continue;
+        if (!FULL && !pivot_step_valid(kt, nk)) continue;
         int next = kt + 1;
-        while (next < 16 && !pivot_step_valid(next, nk)) ++next;
+        if (!FULL) while (next < 16 && !pivot_step_valid(next, nk)) ++next;
         int tag;
         cplx r[NR];
         for (;;) {
