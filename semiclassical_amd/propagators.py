@@ -592,6 +592,10 @@ class HermanKlukPropagator(object):
         The first iteration then runs as usual and the launch sequence of the second one is captured in a HIP graph
         that is replayed for the remaining steps (the row of ``slots`` a step writes is a device-resident cursor, so
         no kernel argument changes between steps).  Only for the fused kernels (device potential descriptor, D <= 64).
+
+        Separable potentials with diagonal width matrices and 16 < D <= 64 advance TWO time steps per launch while the monodromy
+        blocks are known to be diagonal (``sc_hk_step_multi``: the second step's reads come from the memory-side cache; results
+        bit-identical to one launch per step; ``pair_steps = False`` switches it off).
         """
         assert self.dim == potential.dimensions(), "potential has wrong dimensions"
         dt = float(dt)
