@@ -52,6 +52,24 @@ def test_two_steps_per_visit_equal_single_steps(D, n, nt):
     assert int(a._multi["bad"].item()) == 0
 
 
+def test_pairs_equal_single_steps_at_the_benchmark_size():
+    """BASELINE configs[1] at full size (D = 60, n = 10^5: every persistent workgroup draws ~100 trajectories from the cursor): the
+    pair path against one launch per step, bit for bit, and the norm of the determinant's phase factor stays 1 (|sgn| = 1)"""
+    (a, b), pot, E0 = _pair(60, 100000, seed=11)
+    dt, nt = 0.2067, 4                                    # the benchmark's time step (0.005 fs in atomic units)
+    ca, ka = a.run(pot, dt, nt, E0)
+    assert a._multi is not None
+    b.pair_steps = False
+    cb, kb = b.run(pot, dt, nt, E0)
+    assert b._multi is None
+    a.synchronize()
+    b.synchronize()
+    _same_state(a, b)
+    assert np.array_equal(ca, cb) and np.array_equal(ka, kb)
+    assert torch.all(a._sgn.abs() == 1.0) and torch.isfinite(torch.view_as_real(a._c2)).all()
+    assert int(a._flags[-1].item()) == 100000             # the cursor handed out every trajectory exactly once in the last launch
+
+
 def test_pairs_against_the_oracle():
     """the pair path against the CPU oracle (not only against the engine's own one-step kernel)"""
     import bench
