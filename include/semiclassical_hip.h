@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        15
+#define SC_ABI_VERSION        16
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -69,9 +69,11 @@ typedef struct sc_potential {
  *   SC_MONO_ROWMAJOR  [4][D][D]: Mqq, Mqp, Mpq, Mpp one after the other, each row-major (a, b).  Every entry point
  *                     takes this order.
  *   SC_MONO_TILED16   16 x 16 tiles in the order (ra, rb) of tile rows / columns; tile (ra, rb) stores its nra x ncb
- *                     part (nra = min(16, D - 16 ra), ncb likewise) of Mqq, Mqp, Mpq, Mpp one after the other, each
- *                     row-major inside the tile:
- *                         offset(p, a, b) = 4 (16 ra D + 16 nra rb) + p nra ncb + (a - 16 ra) ncb + (b - 16 rb)
+ *                     part (nra = min(16, D - 16 ra), ncb likewise) of the plane PAIR (Mqq, Mqp) element by element
+ *                     (row-major inside the tile, the two planes of an element side by side), then the pair (Mpq, Mpp)
+ *                     the same way (ABI 16; up to ABI 15 the four planes followed one another):
+ *                         offset(p, a, b) = 4 (16 ra D + 16 nra rb) + (p / 2) 2 nra ncb + 2 ((a - 16 ra) ncb + (b - 16 rb)) + p % 2
+ *                     A thread of the fast kernel then moves both planes of a pair with one 16-byte access.
  *                     Identical to SC_MONO_ROWMAJOR for D <= 16.  Only sc_hk_step on its separable / diagonal-width
  *                     fast path takes it (the 16 x 16 thread grid of that kernel then walks a trajectory linearly
  *                     through HBM); sc_mono_convert switches a state between the two in place. */

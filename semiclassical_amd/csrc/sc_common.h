@@ -127,7 +127,9 @@ __host__ __device__ __forceinline__ int64_t sc_mono_offset(int layout, int D, in
     if (layout == SC_MONO_ROWMAJOR) return ((int64_t)p * D + a) * D + b;
     const int ra = a >> 4, rb = b >> 4;
     const int nra = D - 16 * ra < 16 ? D - 16 * ra : 16, ncb = D - 16 * rb < 16 ? D - 16 * rb : 16;
-    return 4 * ((int64_t)16 * ra * D + 16 * nra * rb) + (int64_t)p * nra * ncb + (a & 15) * ncb + (b & 15);
+    // inside a tile: (Mqq, Mqp) element by element, then (Mpq, Mpp) element by element (a thread of the fast kernel moves the two
+    // planes of a pair with ONE 16-byte access; round 4 -- the four planes used to follow one another)
+    return 4 * ((int64_t)16 * ra * D + 16 * nra * rb) + (int64_t)(p >> 1) * 2 * nra * ncb + 2 * ((a & 15) * ncb + (b & 15)) + (p & 1);
 }
 
 // ---- shared by the step kernels ----

@@ -5,6 +5,12 @@
 #pragma once
 #include "sc_common.h"
 
+// -DLU_PIVOT_CLOCK (variant library, tools/lu_pivot_clock.py): the winner lane of every pivot step of workgroup 0 writes the shader
+// clock to g_lu_clock[item][16 KB + kt] for the first 64 items
+#ifdef LU_PIVOT_CLOCK
+static __device__ unsigned long long *g_lu_clock = nullptr;
+#endif
+
 namespace {
 
 template <int CTRL>
@@ -163,6 +169,9 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
         detbuf[16 * KB + kt] = piv;
         __asm__ volatile("" ::: "memory");
         __hip_atomic_store(&pivrec[kt].pad, (seq << 4) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef LU_PIVOT_CLOCK
+        if (g_lu_clock && blockIdx.x == 0 && ((seq - 1 - KB) >> 2) < 64) g_lu_clock[((seq - 1 - KB) >> 2) * 64 + 16 * KB + kt] = clock64();
+#endif
     }
     __asm__ volatile("" ::: "memory");
     // |pivot|^2 more than 2^8 below some |a_kj|^2 outside the block: the pivoted fallback redoes the trajectory

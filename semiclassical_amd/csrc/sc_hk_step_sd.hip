@@ -84,6 +84,7 @@
 namespace {
 
 typedef unsigned int sc_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int sc_v4u __attribute__((ext_vector_type(4)));
 
 // TILED: the monodromy blocks of a trajectory are stored as 16 x 16 tiles (sc_state.mono_layout = 1, see the header):
 // tile (ra, rb) holds its part of Mqq, Mqp, Mpq, Mpp one after the other, each row-major inside the tile.  With the
@@ -207,8 +208,9 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
         const bool rowok_last = 16 * (NR - 1) + til < Dl, colok_last = NCL_BASE + tj < Dl;
         // byte offsets of this thread inside a tile: row-major (row, tj) of a D x D plane; tiled: inside a 16-wide / the
         // last (narrower) column tile
-        const unsigned vo = 8u * (TILED ? (unsigned)(til * 16 + tj) : (unsigned)(til * Dl + tj));
-        const unsigned vol = TILED ? 8u * (unsigned)(til * (Dl - NCL_BASE) + tj) : vo;
+        // tiled: 16 bytes per element of a plane pair (Mqq, Mqp) / (Mpq, Mpp)
+        const unsigned vo = TILED ? 16u * (unsigned)(til * 16 + tj) : 8u * (unsigned)(til * Dl + tj);
+        const unsigned vol = TILED ? 16u * (unsigned)(til * (Dl - NCL_BASE) + tj) : vo;
         auto voffset = [&](int ra, int rb) {
             const unsigned v = rb == NR - 1 ? vol : vo;
             const bool ok = (ra < NR - 1 || rowok_last) && (rb < NR - 1 || colok_last);
@@ -231,10 +233,19 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
                 const int vofs = voffset(ra, rb), base = tile_base(ra, rb), plane = plane_bytes(ra, rb);
+                if constexpr (TILED) {                     // one 16-byte load per plane pair
 #pragma unroll
-                for (int pl = 0; pl < 4; ++pl) {
-                    const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, vofs, base + pl * plane, TILED ? aux : 0);
-                    raw[ra & 1][pl][rb] = __hiloint2double((int)v.y, (int)v.x);
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const sc_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, vofs, base + pp * 2 * plane, aux);
+                        raw[ra & 1][2 * pp][rb] = __hiloint2double((int)v.y, (int)v.x);
+                        raw[ra & 1][2 * pp + 1][rb] = __hiloint2double((int)v.w, (int)v.z);
+                    }
+                } else {
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) {
+                        const sc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, vofs, base + pl * plane, 0);
+                        raw[ra & 1][pl][rb] = __hiloint2double((int)v.y, (int)v.x);
+                    }
                 }
             }
             if (SC_SD_DIRECT_P && do_step) {
@@ -274,11 +285,30 @@ __global__ __launch_bounds__(256, MINW) void hk_step_sd_kernel(StepArgs A, Multi
                     const double nqp = fma(p12, mpp, p11 * mqp), npp = fma(p22, mpp, p21 * mqp);
                     mqq = nqq; mpq = npq; mqp = nqp; mpp = npp;
                     const double out[4] = {mqq, mqp, mpq, mpp};
+                    if constexpr (TILED) {
 #pragma unroll
-                    for (int pl = 0; pl < 4; ++pl) {
-                        sc_v2u v;
-                        v.x = (unsigned)__double2loint(out[pl]); v.y = (unsigned)__double2hiint(out[pl]);
-                        __builtin_amdgcn_raw_buffer_store_b64(v, rs, vofs, base + pl * plane, TILED ? aux_store : 0);
+                        for (int pp = 0; pp < 2; ++pp) {
+                            sc_v4u v;
+                            v.x = (unsigned)__double2loint(out[2 * pp]); v.y = (unsigned)__double2hiint(out[2 * pp]);
+                            v.z = (unsigned)__double2loint(out[2 * pp + 1]); v.w = (unsigned)__double2hiint(out[2 * pp + 1]);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs, vofs, base + pp * 2 * plane, aux_store);
+                            // STORE-DATA HAZARD (found on MI355X, round 4): a buffer store of more than 8 bytes reads its data
+                            // registers over more than one cycle, and a VALU instruction that overwrites them in the next wait
+                            // states changes what is stored (lanes 12..15 of every row of the last wave got Im M' instead of
+                            // Mpq, in 1 % of the trajectories, only with many workgroups in flight).  hipcc's hazard recogniser
+                            // covers the case WITHOUT a scalar offset register only (GCNHazardRecognizer::createsVALUHazard);
+                            // these stores have one.  Three wait states, and nothing is scheduled across them.
+                            __builtin_amdgcn_sched_barrier(0);
+                            __asm__ volatile("s_nop 2");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int pl = 0; pl < 4; ++pl) {
+                            sc_v2u v;
+                            v.x = (unsigned)__double2loint(out[pl]); v.y = (unsigned)__double2hiint(out[pl]);
+                            __builtin_amdgcn_raw_buffer_store_b64(v, rs, vofs, base + pl * plane, 0);
+                        }
                     }
                 }
                 const int bl = (16 * rb + tjl) & 63;
@@ -764,3 +794,9 @@ int sc_launch_step_sd_multi(const StepArgs &a, const sc_multi_scratch &ms, hipSt
     }
     return sc_check_launch("sc_hk_step_multi (two steps per visit)");
 }
+
+#ifdef LU_PIVOT_CLOCK
+extern "C" int sc_lu_pivot_clock(unsigned long long *buf) {       // device buffer of 64 * 64 time stamps, or NULL to switch off
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lu_clock), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif

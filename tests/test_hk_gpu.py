@@ -350,7 +350,7 @@ def test_tiled_monodromy_layout_roundtrip_and_parity(D):
     def offset(p, a, b):
         ra, rb = a // 16, b // 16
         nra, ncb = min(16, D - 16 * ra), min(16, D - 16 * rb)
-        return 4 * (16 * ra * D + 16 * nra * rb) + p * nra * ncb + (a % 16) * ncb + (b % 16)
+        return 4 * (16 * ra * D + 16 * nra * rb) + (p // 2) * 2 * nra * ncb + 2 * ((a % 16) * ncb + (b % 16)) + p % 2
     perm = np.array([offset(p, a, b) for p in range(4) for a in range(D) for b in range(D)])
     assert np.array_equal(np.sort(perm), np.arange(4 * D * D))                 # a bijection
 
