@@ -6,7 +6,8 @@
 #include "sc_common.h"
 
 // -DLU_PIVOT_CLOCK (variant library, tools/lu_pivot_clock.py): the winner lane of every pivot step of workgroup 0 writes the shader
-// clock to g_lu_clock[item][16 KB + kt] for the first 64 items
+// clock to g_lu_clock[item][16 KB + kt][2] for the first 64 items; [0]: the owner's poll of the previous step returned, [1]: its
+// first-slot update is done (publish_pivot_row starts)
 #ifdef LU_PIVOT_CLOCK
 static __device__ unsigned long long *g_lu_clock = nullptr;
 #endif
@@ -153,25 +154,30 @@ __device__ __forceinline__ void publish_pivot_row(const cplx (&m)[NR][NR], cplx 
     const int pl = 15 - (key_blk & 15);
     const int src = __builtin_amdgcn_readfirstlane((lane & ~15) | pl);
     const cplx inv = c_make(readlane_f64(myinv.x, src), readlane_f64(myinv.y, src));
-    // sign of the column choice: the pivot column is the p-th of the live ones (p = live columns to its left; only the
-    // 16 owner lanes are active, so the ballot holds exactly their `live` bits) = p adjacent transpositions
-    const unsigned long long lm = __ballot(live);
-    const int flip = (__popcll(lm & ((1ull << src) - 1ull)) & 1) << 31;
     // no masking of the columns that are not live: their entries in this row are exactly zero already (a pivot column is
     // cleared in every remaining row by its own step: a - a * 1), and the pivot column itself gets r = 1, which clears it
     rowbuf[kt][16 * KB + tj] = c_mul(m[KB][KB], inv);
 #pragma unroll
     for (int rb = KB + 1; rb < NR; ++rb) rowbuf[kt][16 * rb + tj] = c_mul(m[KB][rb], inv);
-    if (tj == pl) {                                       // the winner publishes the pivot itself
-        if (m[KB][KB].x == 0.0 && m[KB][KB].y == 0.0) atomicOr(weak, 2);      // singular: det = 0
+    __asm__ volatile("" ::: "memory");
+    // the tag FIRST: everything below is behind the hand-over (the per-pivot clocks of tools/lu_pivot_clock.py show the workgroup
+    // waiting on this chain: the zero-pivot test alone, moved behind the tag, was worth 2.8 % of the kernel)
+    if (tj == pl) {
+        __hip_atomic_store(&pivrec[kt].pad, (seq << 4) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef LU_PIVOT_CLOCK
+        if (g_lu_clock && blockIdx.x == 0 && ((seq - 1 - KB) >> 2) < 64) g_lu_clock[(((seq - 1 - KB) >> 2) * 64 + 16 * KB + kt) * 4 + 2] = clock64();
+#endif
+    }
+    __asm__ volatile("" ::: "memory");
+    // sign of the column choice: the pivot column is the p-th of the live ones (p = live columns to its left; only the
+    // 16 owner lanes are active, so the ballot holds exactly their `live` bits) = p adjacent transpositions
+    const unsigned long long lm = __ballot(live);
+    const int flip = (__popcll(lm & ((1ull << src) - 1ull)) & 1) << 31;
+    if (tj == pl) {                                       // the winner stores the signed pivot
         const cplx piv = c_make(__hiloint2double(__double2hiint(m[KB][KB].x) ^ flip, __double2loint(m[KB][KB].x)),
                                 __hiloint2double(__double2hiint(m[KB][KB].y) ^ flip, __double2loint(m[KB][KB].y)));
         detbuf[16 * KB + kt] = piv;
-        __asm__ volatile("" ::: "memory");
-        __hip_atomic_store(&pivrec[kt].pad, (seq << 4) | pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef LU_PIVOT_CLOCK
-        if (g_lu_clock && blockIdx.x == 0 && ((seq - 1 - KB) >> 2) < 64) g_lu_clock[((seq - 1 - KB) >> 2) * 64 + 16 * KB + kt] = clock64();
-#endif
+        if (m[KB][KB].x == 0.0 && m[KB][KB].y == 0.0) atomicOr(weak, 2);      // singular: det = 0
     }
     __asm__ volatile("" ::: "memory");
     // |pivot|^2 more than 2^8 below some |a_kj|^2 outside the block: the pivoted fallback redoes the trajectory
@@ -230,12 +236,20 @@ __device__ __forceinline__ void eliminate_block(cplx (&m)[NR][NR], cplx *detbuf,
             if ((tag >> 4) == seq) break;
         }
         const int pl = tag & 15;
+#ifdef LU_PIVOT_CLOCK
+        if (g_lu_clock && blockIdx.x == 0 && next < 16 && ti == next && tj == 0 && ((seq - 1 - KB) >> 2) < 64)
+            g_lu_clock[(((seq - 1 - KB) >> 2) * 64 + 16 * KB + next) * 4 + 0] = clock64();
+#endif
         live = live && tj != pl;
         cplx c[NR];
         // rows of this block that have been pivot rows already are updated like the others: nothing reads them again
         column_fetch<NR, KB>(m, c, pl);
 #pragma unroll
         for (int rb = KB; rb < NR; ++rb) m[KB][rb] = c_fnma(c[KB], r[rb], m[KB][rb]);
+#ifdef LU_PIVOT_CLOCK
+        if (g_lu_clock && blockIdx.x == 0 && next < 16 && ti == next && tj == 0 && ((seq - 1 - KB) >> 2) < 64)
+            g_lu_clock[(((seq - 1 - KB) >> 2) * 64 + 16 * KB + next) * 4 + 1] = clock64();
+#endif
         if (next < 16 && ti == next) publish_pivot_row<NR, KB, RW>(m, detbuf, live, next, seq, rowbuf, pivrec, weak, tid);
 #pragma unroll
         for (int ra = KB + 1; ra < NR; ++ra) {

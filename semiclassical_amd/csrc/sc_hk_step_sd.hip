@@ -796,7 +796,7 @@ int sc_launch_step_sd_multi(const StepArgs &a, const sc_multi_scratch &ms, hipSt
 }
 
 #ifdef LU_PIVOT_CLOCK
-extern "C" int sc_lu_pivot_clock(unsigned long long *buf) {       // device buffer of 64 * 64 time stamps, or NULL to switch off
+extern "C" int sc_lu_pivot_clock(unsigned long long *buf) {       // device buffer of 64 * 64 * 4 time stamps, or NULL to switch off
     return hipMemcpyToSymbol(HIP_SYMBOL(g_lu_clock), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
 }
 #endif

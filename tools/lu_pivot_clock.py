@@ -34,13 +34,13 @@ def main():
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
-    buf = torch.zeros(64 * 64, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(64 * 64 * 4, dtype=torch.int64, device="cuda")
     assert so.sc_lu_pivot_clock(ctypes.c_void_p(buf.data_ptr())) == 0
     launch()
     torch.cuda.synchronize()
     assert so.sc_lu_pivot_clock(None) == 0
-    t = buf.cpu().numpy().reshape(64, 64).astype(np.int64)
-    t = t[8:56]                                                  # skip the start-up and the tail of the launch
+    full = buf.cpu().numpy().reshape(64, 64, 4).astype(np.int64)[8:56]
+    t = full[:, :, 2]                                                  # skip the start-up and the tail of the launch
     print(f"# D = {dim}, n = {n}: shader-clock cycles between consecutive pivot publications, workgroup 0, mean over {len(t)} items")
     nr = (dim + 15) // 16
     for kb in range(nr):
@@ -53,6 +53,14 @@ def main():
             continue
         print(f"block {kb} (N = {nr - kb}): {len(order)} steps, {d.mean():7.0f} cycles per step (min {d.min()}, median {np.median(d):.0f}, max {d.max()}); "
               f"block total {(stamps[:, -1] - stamps[:, 0]).mean():8.0f}")
+        # inside a step: poll of the previous record returned -> first-slot update done -> record published -> next owner's poll returns
+        idx = [16 * kb + kt for kt in order[1:]]
+        prev = [16 * kb + kt for kt in order[:-1]]
+        wait = full[:, idx, 0] - full[:, prev, 2]
+        upd = full[:, idx, 1] - full[:, idx, 0]
+        pub = full[:, idx, 2] - full[:, idx, 1]
+        print(f"    publication -> next owner has the row: {np.median(wait):6.0f} | column fetch + first-slot update: {np.median(upd):6.0f} | "
+              f"search, inverse, scaling, publication: {np.median(pub):6.0f}   (medians, cycles)")
         if kb + 1 < nr:
             nxt = t[:, 16 * (kb + 1)]
             print(f"    hand-over to block {kb + 1}: {(nxt - stamps[:, -1]).mean():7.0f} cycles")
