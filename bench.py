@@ -526,8 +526,8 @@ def main():
                          "steps_per_launch": per,
                          "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": abytes,
-                         "also_bound_by": ("FP64 VALU issue in the elimination: with the second step's reads out of the way the streaming "
-                                           "phase alone takes 2.94 ms per step, the elimination-bound launch 3.8 (profiles/r4_sd_phases.txt)"
+                         "also_bound_by": ("the pivot hand-over chain of the 60 x 60 complex elimination (latency, not bytes): the streaming phase "
+                                           "alone runs at 2.8 ms per step in this mode (profiles/r4_sd_phases.txt, r4_lu_pivot_clock.txt) "
                                            if per == 2 else None)},
             "C_auto_last": [float(cauto[-1].real), float(cauto[-1].imag)],
         }
