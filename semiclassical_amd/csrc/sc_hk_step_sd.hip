@@ -789,7 +789,14 @@ int sc_launch_step_sd_multi(const StepArgs &a, const sc_multi_scratch &ms, hipSt
     switch (nr) {
         case 2: hipLaunchKernelGGL((hk_step_sd_kernel<2, 4, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break;
         case 3: hipLaunchKernelGGL((hk_step_sd_kernel<3, 4, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break;
-        case 4: hipLaunchKernelGGL((hk_step_sd_kernel<4, 4, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break;
+        case 4:
+#ifdef SC_TUNING
+            if (const char *occ_env = getenv("SC_SD_OCC")) {
+                if (atoi(occ_env) == 3) { hipLaunchKernelGGL((hk_step_sd_kernel<4, 3, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break; }
+                if (atoi(occ_env) == 2) { hipLaunchKernelGGL((hk_step_sd_kernel<4, 2, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break; }
+            }
+#endif
+            hipLaunchKernelGGL((hk_step_sd_kernel<4, 4, true, true, 2>), dim3(grid), dim3(256), 0, s, a, ma); break;
         default: return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_step_multi: D = %d", D);
     }
     return sc_check_launch("sc_hk_step_multi (two steps per visit)");
