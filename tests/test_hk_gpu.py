@@ -50,7 +50,7 @@ def test_hk_matches_reference_golden(name):
     assert cases.rel_err(cauto, g["cauto"]) < NORTH_STAR and cases.rel_err(kic, g["kic"]) < NORTH_STAR
 
 
-@pytest.mark.parametrize("name", ["hk_as5_chi002", "hk_methylium", "hk_as60_dt20"])
+@pytest.mark.parametrize("name", ["hk_as5_chi002", "hk_methylium", "hk_as60_dt20", "hk_as60_n96", "hk_as33"])
 def test_fused_run_equals_stepwise_api(name):
     """run() (no host sync inside the loop) returns what the reference loop returns"""
     from tests.engine_cases import engine_potential, engine_propagator

@@ -88,10 +88,12 @@ def test_pairs_against_the_oracle():
     assert cases.rel_err(a._c2.cpu().numpy(), ref.c2.numpy()) < 1e-9
 
 
-def test_golden_as60_through_pairs():
-    """the reference's golden C(t), k_ic(t) of the 60-mode model through the pair path"""
+@pytest.mark.parametrize("name", ["hk_as60", "hk_as60_dt20", "hk_as60_n96", "hk_as33"])
+def test_goldens_through_pairs(name):
+    """the reference's golden C(t), k_ic(t) of the 60- and 33-mode models through the pair path (hk_as60_n96: 96 trajectories, 40 steps
+    of ten times the benchmark's time step, 46 branch-cut crossings of the prefactor in the reference)"""
     from tests.engine_cases import engine_potential, engine_propagator
-    g = cases.load("hk_as60")
+    g = cases.load(name)
     pot, prop = engine_potential(g), engine_propagator(g)
     c, k = prop.run(pot, float(g["dt"]), int(g["nt"]), float(g["E0"]))
     assert prop._multi is not None

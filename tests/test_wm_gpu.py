@@ -38,7 +38,7 @@ def test_wm_matches_reference_golden(name):
     assert cases.rel_err(kic, g["kic"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["wm_methylium", "wm_as5_chi002"])
+@pytest.mark.parametrize("name", ["wm_methylium", "wm_as5_chi002", "wm_as24"])
 def test_wm_fused_run(name):
     from tests.engine_cases import engine_potential, engine_propagator
     g = cases.load(name)
