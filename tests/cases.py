@@ -11,7 +11,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 HK_CASES = ["hk_1d", "hk_as5_chi000", "hk_as5_chi002", "hk_as60", "hk_as60_dt20", "hk_methylium",
             "hk_as60_n96", "hk_as33"]          # round 4 (tests/golden/make_golden_round4.py): more trajectories / steps at D = 60, D = 33
 GDML_CASES = ["hk_coumarin_gdml"]
-WM_CASES = ["wm_1d", "wm_as5_chi002", "wm_methylium", "wm_as24"]          # wm_as24: D > 16 (round 4)
+WM_CASES = ["wm_1d", "wm_as5_chi002", "wm_methylium", "wm_as24", "wm_as60"]          # wm_as24, wm_as60: D > 16 (round 4)
 
 
 def load(name):

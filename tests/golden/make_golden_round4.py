@@ -7,6 +7,7 @@ compatibility aliases and for what a file holds):
                 run() is checked against
   hk_as33       the first 33 modes of the same model (three 16-row slots in the fast kernel), 64 trajectories, 30 steps
   wm_as24       Walton-Manolopoulos on the first 24 modes (D > 16: the LDS / global-scratch WM kernel), 24 trajectories, 8 steps
+  wm_as60       Walton-Manolopoulos on all 60 modes, 12 trajectories, 4 steps
 """
 import os
 import sys
@@ -37,6 +38,9 @@ def main():
     mg.run_case("hk_as33", lambda: HermanKlukPropagator(G, G), pot, dQ, 0.0 * dQ, G, 20 * dt, 30, E0, 64, [1, 30], ex, store_y=False)
     omega, dQ, pot, G, E0, ex = model(24)
     mg.run_case("wm_as24", lambda: WaltonManolopoulosPropagator(G, G, 500, 500), pot, dQ, 0.0 * dQ, G, 20 * dt, 8, E0, 24, [1, 8],
+                dict(ex, alpha=500.0, beta=500.0), store_y=False)
+    omega, dQ, pot, G, E0, ex = model(60)
+    mg.run_case("wm_as60", lambda: WaltonManolopoulosPropagator(G, G, 500, 500), pot, dQ, 0.0 * dQ, G, 20 * dt, 4, E0, 12, [1, 4],
                 dict(ex, alpha=500.0, beta=500.0), store_y=False)
 
 
