@@ -402,6 +402,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-configuration lines and the 2000-step run")
     ap.add_argument("--no-pairs", action="store_true", help="A/B: one step-kernel launch per time step instead of two steps per visit")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of the multi-rank flow on a one-GPU box: every rank runs on cuda:0, process group over gloo; the line is "
+                         "marked and its numbers mean nothing")
     ap.add_argument("--config", choices=["1", "3", "3hk", "5"], default=None,
                     help="run ONLY that BASELINE configuration's side measurement (for one rocprofv3 summary per configuration: "
                          "1 = 5-mode AS at n = 1e5, 3 = methylium WM at n = 1e5, 5 = 30-atom sGDML at n = 1e4) and print its JSON")
@@ -426,8 +429,12 @@ def main():
         print(json.dumps({f"config{args.config}": fn(dev, *fargs)}), flush=True)
         return
     from semiclassical_amd import distributed as D
+    if args.share_gpu:
+        os.environ["SC_DIST_BACKEND"] = "gloo"
     rank, world, local = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -512,7 +519,7 @@ def main():
                                 "(configs[1]): per-GPU work differs by 25 %, the metric is a rate and the kernel's rate does not "
                                 "depend on n at this size" if (n_total == 1000000 and world == 8) else "")),
             "backend": backend, "ranks": ranks,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not args.share_gpu else "synthetic; REHEARSAL (--share-gpu): all ranks on one GPU, not a measurement",
             "config": {"workload": "anharmonic-AS 60-mode, HK, fp64, dt=0.005 fs (BASELINE.json configs[1]"
                                    + ("; 10^6 trajectories over 8 GPUs = configs[3])" if n_total == 1000000 and world == 8 else ")"),
                        "trajectories_per_gpu": n, "trajectories_total": n_total, "dim": dim,

@@ -281,3 +281,27 @@ def test_driver_command_line_shares_batches_among_ranks(tmp_path):
     assert int(res[2]["trajectories"]) == 1400
     assert cases.rel_err(res[2]["autocorrelation"], res[1]["autocorrelation"]) < 1e-12
     assert cases.rel_err(res[2]["ic_correlation"], res[1]["ic_correlation"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bench_flow_with_two_ranks_sharing_the_gpu():
+    """bench.py's multi-rank flow end to end (barriers, max over ranks, gathered rank table, one flush) as torch.distributed.run starts
+    it, rehearsed on ONE GPU (--share-gpu: gloo, both ranks on cuda:0): the two shards of one global ensemble reproduce the
+    single-process correlation function of the same ensemble"""
+    import json
+    import subprocess
+    import sys
+    from semiclassical_amd import distributed as D
+    common = ["--steps", "4", "--warmup", "1", "--no-configs", "--no-cpu-baseline", "--ntraj-total", "3000"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=300, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(D.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + common,
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert b["n_gpus"] == 2 and [r["trajectories"] for r in b["ranks"]] == [1500, 1500] and "REHEARSAL" in b["data"]
+    assert a["config"]["trajectories_total"] == b["config"]["trajectories_total"] == 3000
+    assert np.allclose(a["C_auto_last"], b["C_auto_last"], rtol=1e-12, atol=1e-14)
