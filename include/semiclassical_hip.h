@@ -37,7 +37,7 @@ extern "C" {
 
 /* Bumped on every change of a struct layout or a function signature below.  semiclassical_amd/_lib.py refuses a
  * library whose sc_abi_version() or struct sizes differ from its own declarations. */
-#define SC_ABI_VERSION        16
+#define SC_ABI_VERSION        17
 
 #define SC_OK                 0
 #define SC_ERR_BAD_ARGUMENT  -1
@@ -306,6 +306,19 @@ int sc_hk_run_supported(const sc_potential *pot, const sc_hk_consts *hk, const s
 int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
               const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,
               double dt, int32_t nsteps, double *partials, double *slots_out, double *elog, void *stream);
+
+/* sc_hk_run for a CONSTANT dense Hessian with the monodromy blocks of the state in NORMAL-MODE coordinates (round 4).  RK4 of a
+ * linear system commutes with a change of basis: with W = m^-1/2 H m^-1/2 = U diag(lambda) U^T, A = m^-1/2 U, B = m^1/2 U and
+ *     Mqq~ = A^-1 Mqq A,  Mqp~ = A^-1 Mqp B,  Mpq~ = B^-1 Mpq A,  Mpp~ = B^-1 Mpp B
+ * the step matrix Phi(dt) of sc_potential.lin_prop becomes 2 x 2 per mode, mode_prop[a] = (phi_qq, phi_qp, phi_pq, phi_pp)_a =
+ * the RK4 polynomial of dt [[0, 1], [-lambda_a, 0]], and the prefactor is the same expression of the transformed blocks with
+ * L1 A, L2 B, A^-1 R1, B^-1 R2 as the prefactor constants -- real, dense: diag = 0.  The CALLER transforms st->mono before the call and back
+ * after it (HermanKlukPropagator.run does, with two batched products); (q, p, S), the correlation terms and the energy guard are
+ * in the original coordinates as in sc_hk_run.  Per lane and step 8 D multiply-adds replace the 8 D^2 of the product with Phi. */
+int sc_hk_run_modal_supported(const sc_potential *pot, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0);
+int sc_hk_run_modal(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
+                    const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,
+                    double dt, int32_t nsteps, const double *mode_prop, double *partials, double *slots_out, double *elog, void *stream);
 
 /* Walton-Manolopoulos: Filinov matrix A (eqn 50), its inverse and determinant, Gt/Gti/CQQ/M (57-78), the second
  * inverse and determinant, the trackers of sqrt(detA), sqrt(detM) and the per-trajectory terms of eqns (85), (100),

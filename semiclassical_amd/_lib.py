@@ -78,7 +78,7 @@ SC_MONO_ROWMAJOR, SC_MONO_TILED16 = 0, 1
 
 # every symbol include/semiclassical_hip.h declares: name -> (restype, argtypes)
 P = C.POINTER
-ABI_VERSION = 16              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
+ABI_VERSION = 17              # = SC_ABI_VERSION of include/semiclassical_hip.h these declarations were written against
 STRUCTS = (sc_potential, sc_state, sc_hk_consts, sc_overlap_consts, sc_nac_consts, sc_wm_consts, sc_gdml_model,
            sc_dense_scratch, sc_multi_scratch)
 
@@ -109,6 +109,10 @@ SIGNATURES = {
     "sc_hk_run": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), P(sc_overlap_consts), P(sc_nac_consts), c_double_p,
                             c_double_p, c_double_p, C.c_double, C.c_double, C.c_int32, c_double_p, c_double_p, c_double_p,
                             C.c_void_p]),
+    "sc_hk_run_modal_supported": (C.c_int, [P(sc_potential), P(sc_hk_consts), P(sc_overlap_consts)]),
+    "sc_hk_run_modal": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), P(sc_overlap_consts), P(sc_nac_consts), c_double_p,
+                                  c_double_p, c_double_p, C.c_double, C.c_double, C.c_int32, c_double_p, c_double_p, c_double_p,
+                                  c_double_p, C.c_void_p]),
     "sc_energy_guard": (C.c_int, [c_double_p, C.c_int32, C.c_double, c_double_p, C.c_void_p]),
     "sc_wm_grid": (C.c_int, [C.c_int64, C.c_int32]),
     "sc_wm_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),

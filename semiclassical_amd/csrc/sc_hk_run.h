@@ -13,6 +13,7 @@ struct RunArgs {
     int nsteps;
     double *partials;           // [nsteps][slots][5]: Re C, Im C, Re k, Im k, sum of (T+V) at the k4 stage; zeroed by the caller
     int slots;                  // 4 * gridDim.x
+    const double *mode_prop;    // sc_hk_run_modal: [D][4] per-mode step matrices (the blocks are in normal-mode coordinates), else NULL
 };
 
 // sc_hk_run_lin.hip: 1 = the shape (D, d', diagonal widths) is instantiated (and, with launch != 0, was launched), 0 = not,

@@ -33,8 +33,14 @@ struct RunLinLayout {
 #ifndef SC_RUNLIN_OCC
 #define SC_RUNLIN_OCC 2
 #endif
-template <int D, int DP, bool DIAG>
-__global__ __launch_bounds__(256, SC_RUNLIN_OCC) void hk_run_lin_kernel(RunArgs R) {
+#ifndef SC_RUNLIN_MODAL_OCC
+#define SC_RUNLIN_MODAL_OCC 2
+#endif
+// MODAL (round 4, sc_hk_run_modal): the monodromy blocks of the state are in NORMAL-MODE coordinates (the caller transformed them and
+// the prefactor constants), where the step matrix is 2 x 2 per mode: row a of the blocks is multiplied by (phi_qq, phi_qp; phi_pq,
+// phi_pp)_a -- 8 D plain multiply-adds per lane and step instead of the 8 D^2 broadcast multiply-adds of the product with Phi.
+template <int D, int DP, bool DIAG, bool MODAL>
+__global__ __launch_bounds__(256, MODAL ? SC_RUNLIN_MODAL_OCC : SC_RUNLIN_OCC) void hk_run_lin_kernel(RunArgs R) {
     typedef RunLinLayout<D, DP, DIAG> L;
     constexpr int W = 2 * D, DD = D * D, N = DIAG ? D : DP;
     constexpr int PH = L::PH, PP = L::PP, PL = L::PL, PR = L::PR, PD = L::PD;
@@ -78,10 +84,17 @@ __global__ __launch_bounds__(256, SC_RUNLIN_OCC) void hk_run_lin_kernel(RunArgs 
             sR2[i * PR + j] = i < D ? A.hk.R2[2 * (i * DP + j)] : 0.0;
         }
     }
-    for (int e = tid; e < 16 * 4 * D; e += 256) {
-        const int i = e / (4 * D), k = e - i * 4 * D, blk = k / D, g = k - blk * D;      // blk: qq, qp, pq, pp
-        const int row = (blk >> 1) * D + i, col = (blk & 1) * D + g;
-        sPhi[i * PP + k] = i < D ? A.pot.lin_prop[row * W + col] : 0.0;
+    if (MODAL) {
+        for (int e = tid; e < 16 * 4; e += 256) {
+            const int i = e >> 2, k = e & 3;                                              // (phi_qq, phi_qp, phi_pq, phi_pp) of mode i
+            sPhi[i * PP + k] = i < D ? R.mode_prop[i * 4 + k] : (k == 0 || k == 3 ? 1.0 : 0.0);
+        }
+    } else {
+        for (int e = tid; e < 16 * 4 * D; e += 256) {
+            const int i = e / (4 * D), k = e - i * 4 * D, blk = k / D, g = k - blk * D;      // blk: qq, qp, pq, pp
+            const int row = (blk >> 1) * D + i, col = (blk & 1) * D + g;
+            sPhi[i * PP + k] = i < D ? A.pot.lin_prop[row * W + col] : 0.0;
+        }
     }
     if (tid < 16) {
         const bool in = tid < D;
@@ -208,6 +221,17 @@ __global__ __launch_bounds__(256, SC_RUNLIN_OCC) void hk_run_lin_kernel(RunArgs 
             }
             // ---- [X; Y] <- Phi [X; Y], one half (Mqq, Mpq | Mqp, Mpp) at a time: row g of the old blocks comes from lane g
             //      inside the multiply-add, Phi[r][g] from LDS ----
+            if constexpr (MODAL) {
+                const double fqq = cPhi[r * PP], fqp = cPhi[r * PP + 1], fpq = cPhi[r * PP + 2], fpp = cPhi[r * PP + 3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int b = 0; b < D; ++b) {
+                        const double tq = cur[h][0][b], tp = cur[h][1][b];
+                        cur[h][0][b] = fma(fqp, tp, fqq * tq);
+                        cur[h][1][b] = fma(fpp, tp, fpq * tq);
+                    }
+            } else
             sfor<0, 2>([&](auto hc) {
                 constexpr int h = decltype(hc)::value;
                 double (&Tq)[D] = cur[h][0], (&Tp)[D] = cur[h][1];
@@ -317,16 +341,23 @@ __global__ __launch_bounds__(256, SC_RUNLIN_OCC) void hk_run_lin_kernel(RunArgs 
     }
 }
 
-template <int D, int DP, bool DIAG>
-int launch(const RunArgs &a, int grid, hipStream_t s, int do_launch) {
-    if (!do_launch) return 1;
+template <int D, int DP, bool DIAG, bool MODAL>
+int launch_one(const RunArgs &a, int grid, hipStream_t s) {
     const size_t lds = RunLinLayout<D, DP, DIAG>::bytes;
-    if (hipFuncSetAttribute((const void *)hk_run_lin_kernel<D, DP, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+    if (hipFuncSetAttribute((const void *)hk_run_lin_kernel<D, DP, DIAG, MODAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
         return sc_check_launch("sc_hk_run (LDS attribute)");
-    hipLaunchKernelGGL((hk_run_lin_kernel<D, DP, DIAG>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((hk_run_lin_kernel<D, DP, DIAG, MODAL>), dim3(grid), dim3(256), lds, s, a);
     const int rc = sc_check_launch("sc_hk_run (constant-Hessian whole-loop kernel)");
     return rc == SC_OK ? 1 : rc;
+}
+template <int D, int DP, bool DIAG>
+int launch(const RunArgs &a, int grid, hipStream_t s, int do_launch) {
+    if (a.mode_prop) {
+        if constexpr (DIAG) return 0;            // the transformed prefactor constants are dense: no modal kernel for diagonal widths
+        else return do_launch ? launch_one<D, DP, DIAG, true>(a, grid, s) : 1;
+    }
+    return do_launch ? launch_one<D, DP, DIAG, false>(a, grid, s) : 1;
 }
 
 }  // namespace

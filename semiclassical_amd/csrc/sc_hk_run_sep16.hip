@@ -216,11 +216,13 @@ extern "C" int sc_hk_run_slots(int64_t n, int32_t dim) {
 }
 
 // constant dense Hessian with its step matrix, D <= 16 at the shapes sc_hk_run_lin.hip instantiates (real L, R)
-static bool run_lin_shape(const sc_potential *pot, const sc_hk_consts *hk) {
-    if (pot->kind != SC_POT_HARMONIC_DENSE || !pot->lin_prop || pot->dim > 16 || hk->dim != pot->dim) return false;
+static bool run_lin_shape(const sc_potential *pot, const sc_hk_consts *hk, bool modal = false) {
+    if (pot->kind != SC_POT_HARMONIC_DENSE || (!modal && !pot->lin_prop) || pot->dim > 16 || hk->dim != pot->dim) return false;
+    static const double some = 0.0;
     RunArgs probe{};
     probe.step.st.dim = pot->dim;
     probe.step.hk = *hk;
+    probe.mode_prop = modal ? &some : nullptr;
     return sc_launch_run_lin(probe, 0, nullptr, 0) == 1;
 }
 
@@ -231,18 +233,44 @@ extern "C" int sc_hk_run_supported(const sc_potential *pot, const sc_hk_consts *
     return run_lin_shape(pot, hk) ? 1 : 0;
 }
 
+static int run_whole_loop(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
+                          const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,
+                          double dt, int32_t nsteps, const double *mode_prop, double *partials, double *slots_out, double *elog, void *stream);
+
 extern "C" int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
                          const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,
                          double dt, int32_t nsteps, double *partials, double *slots_out, double *elog, void *stream) {
+    return run_whole_loop(pot, st, hk, ovl_t0, nc, vi, probi, nacq, mc_norm, dt, nsteps, nullptr, partials, slots_out, elog, stream);
+}
+
+extern "C" int sc_hk_run_modal_supported(const sc_potential *pot, const sc_hk_consts *hk, const sc_overlap_consts *ovl) {
+    if (!pot || !hk || !ovl) return 0;
+    return run_lin_shape(pot, hk, true) ? 1 : 0;
+}
+
+extern "C" int sc_hk_run_modal(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
+                               const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,
+                               double dt, int32_t nsteps, const double *mode_prop, double *partials, double *slots_out, double *elog,
+                               void *stream) {
+    if (!mode_prop) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run_modal: null mode_prop");
+    if (!pot || !hk || !ovl_t0 || !sc_hk_run_modal_supported(pot, hk, ovl_t0))
+        return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_run_modal: needs a constant dense Hessian and dense real prefactor constants at an "
+                       "instantiated shape D <= 16 (use sc_hk_run)");
+    return run_whole_loop(pot, st, hk, ovl_t0, nc, vi, probi, nacq, mc_norm, dt, nsteps, mode_prop, partials, slots_out, elog, stream);
+}
+
+static int run_whole_loop(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
+                          const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,
+                          double dt, int32_t nsteps, const double *mode_prop, double *partials, double *slots_out, double *elog, void *stream) {
     if (!pot || !st || !hk || !ovl_t0 || !vi || !probi || !partials || !slots_out || !elog)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: null argument");
     if (nc && !nacq) return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: nac constants without nacq");
-    if (!sc_hk_run_supported(pot, hk, ovl_t0))
+    if (!mode_prop && !sc_hk_run_supported(pot, hk, ovl_t0))
         return sc_fail(SC_ERR_UNSUPPORTED, "sc_hk_run: needs a separable potential with diagonal width matrices and D <= %d, or a "
                        "constant dense Hessian with its step matrix (sc_potential.lin_prop) at an instantiated shape D <= 16 "
                        "(use the step-by-step entry points)", SC_SEP16_MAX_D);
     const bool lin = pot->kind == SC_POT_HARMONIC_DENSE;
-    if (lin && pot->lin_dt != dt)
+    if (lin && !mode_prop && pot->lin_dt != dt)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: the step matrix was built for dt = %g, the call asks for %g", pot->lin_dt, dt);
     if (pot->dim != st->dim || hk->dim != st->dim || ovl_t0->dim != st->dim)
         return sc_fail(SC_ERR_BAD_ARGUMENT, "sc_hk_run: dimension mismatch");
@@ -255,6 +283,7 @@ extern "C" int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_h
     if (nc) a.nc = *nc; else a.nc = sc_nac_consts{};
     a.vi = vi; a.probi = probi; a.nacq = nacq; a.mc_norm = mc_norm; a.nsteps = nsteps; a.partials = partials;
     a.slots = sc_hk_run_slots(st->n, st->dim);
+    a.mode_prop = mode_prop;
     if (hipMemsetAsync(partials, 0, sizeof(double) * 5 * (size_t)a.slots * (size_t)nsteps, s) != hipSuccess)
         return sc_check_launch("sc_hk_run (partials)");
     const int grid = a.slots / 4, D = st->dim;

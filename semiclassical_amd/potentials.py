@@ -262,6 +262,25 @@ class MolecularHarmonicPotential(_MolecularPotentialBase):
     def _has_step_matrix(self):
         return self._dim <= 16
 
+    def _normal_modes(self, dt):
+        """RK4 of the monodromy equations in normal-mode coordinates (``sc_hk_run_modal``, include/semiclassical_hip.h): with
+        W = m^-1/2 hess0 m^-1/2 = U diag(lam) U^T the step matrix Phi(dt) of ``_step_matrix`` is T diag-by-mode(phi_a) T^-1,
+        T = blockdiag(A, B), A = m^-1/2 U, B = m^1/2 U (the RK4 polynomial commutes with the change of basis).
+        Returns (A, B, A^-1, B^-1, phi[D][4] = (phi_qq, phi_qp, phi_pq, phi_pp) per mode) as float64 arrays."""
+        m = self._masses.numpy().astype(np.float64)
+        h = self.hess0.numpy().astype(np.float64)
+        sm = np.sqrt(m)
+        lam, U = np.linalg.eigh(0.5 * (h + h.T) / np.outer(sm, sm))
+        A, B = U / sm[:, None], U * sm[:, None]
+        Ainv, Binv = U.T * sm[None, :], U.T / sm[None, :]
+        phi = np.zeros((self._dim, 4))
+        one = np.eye(2, dtype=np.longdouble)
+        for a in range(self._dim):
+            hG = np.longdouble(dt) * np.array([[0.0, 1.0], [-lam[a], 0.0]], dtype=np.longdouble)
+            P = one + hG @ (one + hG @ (one + hG @ (one + hG / 4) / 3) / 2)
+            phi[a] = [P[0, 0], P[0, 1], P[1, 0], P[1, 1]]
+        return A, B, Ainv, Binv, phi
+
     def harmonic_approximation(self, r):
         dev = r.device
         pos0, grad0, hess0 = self.pos0.to(dev), self.grad0.to(dev), self.hess0.to(dev)

@@ -612,7 +612,7 @@ class HermanKlukPropagator(object):
         desc = self._potential_descriptor(potential, dt) if fused else None
         if fused and self._whole_loop_applies(desc):
             # separable potential, diagonal widths, D <= 12: the whole loop as ONE launch (sc_hk_run)
-            self._run_whole_loop(desc, dt, nt, slots)
+            self._run_whole_loop(desc, dt, nt, slots, potential)
         elif use_graph and fused and nt > 2 and not getattr(self, "profile_step_kernel", False) and not self.kernel_timing:
             self._run_graph(potential, dt, nt, desc, slots)
         else:
@@ -645,7 +645,42 @@ class HermanKlukPropagator(object):
                 and not self._shortcut_applies(desc)
                 and bool(lib.sc_hk_run_supported(desc, self._hk, self._ovl_t0)))
 
-    def _run_whole_loop(self, desc, dt, nt, slots):
+    # run() with a constant dense Hessian: from this many steps on the loop runs in normal-mode coordinates (sc_hk_run_modal; the two
+    # changes of basis of the monodromy blocks cost about as much as four steps of the product with Phi)
+    normal_modes_from = 16
+
+    def _modal_constants(self, potential, desc, dt):
+        """transformed prefactor constants and per-mode step matrices for sc_hk_run_modal, or None where it does not apply"""
+        if (desc.kind != _lib.SC_POT_HARMONIC_DENSE or self._pre.diag or not hasattr(potential, "_normal_modes")
+                or not self._hk.real_lr or not lib.sc_hk_run_modal_supported(desc, self._hk, self._ovl_t0)):
+            return None
+        cache = self.__dict__.setdefault("_modal_cache", {})
+        key = (float(dt), potential.hess0.numpy().tobytes(), potential._masses.numpy().tobytes())      # the VALUES: edited in place = new key
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        A, B, Ainv, Binv, phi = potential._normal_modes(dt)
+        dev = self.device
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        L1, L2, R1, R2 = (m.real.numpy() for m in (self._pre.L1, self._pre.L2, self._pre.R1, self._pre.R2))
+        consts = [t((L1 @ A).astype(np.complex128)), t((L2 @ B).astype(np.complex128)),
+                  t((Ainv @ R1).astype(np.complex128)), t((Binv @ R2).astype(np.complex128))]
+        hk = sc_hk_consts(dim=self.dim, dprime=self._pre.dprime, diag=0, real_lr=1,
+                          L1=ptr(consts[0]), L2=ptr(consts[1]), R1=ptr(consts[2]), R2=ptr(consts[3]))
+        hit = {"hk": hk, "consts": consts, "phi": t(phi), "A": t(A), "B": t(B), "Ainv": t(Ainv), "Binv": t(Binv)}
+        cache.clear()
+        cache[key] = hit
+        return hit
+
+    def _to_normal_modes(self, modal, forward):
+        """monodromy blocks <-> normal-mode coordinates, in place: Mqq~ = A^-1 Mqq A, Mqp~ = A^-1 Mqp B, Mpq~ = B^-1 Mpq A, Mpp~ = B^-1 Mpp B"""
+        M = self._mono.view(self.ntraj, 4, self.dim, self.dim)
+        A, B, Ai, Bi = modal["A"], modal["B"], modal["Ainv"], modal["Binv"]
+        pairs = ((Ai, A), (Ai, B), (Bi, A), (Bi, B)) if forward else ((A, Ai), (A, Bi), (B, Ai), (B, Bi))
+        for p, (left, right) in enumerate(pairs):
+            M[:, p] = torch.matmul(left, torch.matmul(M[:, p], right))
+
+    def _run_whole_loop(self, desc, dt, nt, slots, potential=None):
         if desc.kind not in (_lib.SC_POT_MORSE, _lib.SC_POT_HARMONIC_SEP, _lib.SC_POT_EPS_MORSE):
             self._blocks_structurally_diagonal = False
         self._sync_dense_mono(leave_diagonal=True)
@@ -657,11 +692,19 @@ class HermanKlukPropagator(object):
         chunk = min(nt, 512)
         partials = torch.empty((chunk, nslots, 5), dtype=F64, device=self.device)
         nac = self._nac
+        modal = self._modal_constants(potential, desc, dt) if nt >= self.normal_modes_from else None
+        if modal is not None:
+            self._to_normal_modes(modal, forward=True)
         for k0 in range(0, nt, chunk):
             k = min(chunk, nt - k0)
-            check(lib.sc_hk_run(desc, self._state, self._hk, self._ovl_t0, nac, ptr(self._vi), ptr(self.probi),
-                                ptr(self._nacq) if nac is not None else None, self._mc_norm(), dt, k, ptr(partials),
-                                slots.data_ptr() + 40 * k0, ptr(self._elog), self._stream()))
+            tail = (ptr(partials), slots.data_ptr() + 40 * k0, ptr(self._elog), self._stream())
+            head = (self._ovl_t0, nac, ptr(self._vi), ptr(self.probi), ptr(self._nacq) if nac is not None else None, self._mc_norm(), dt, k)
+            if modal is not None:
+                check(lib.sc_hk_run_modal(desc, self._state, modal["hk"], *head, ptr(modal["phi"]), *tail))
+            else:
+                check(lib.sc_hk_run(desc, self._state, self._hk, *head, *tail))
+        if modal is not None:
+            self._to_normal_modes(modal, forward=False)
         self._run_scratch = partials          # alive until the stream has consumed it
         self._nsteps += nt
         for _ in range(nt):

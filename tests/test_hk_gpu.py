@@ -736,3 +736,31 @@ def test_whole_loop_constant_hessian_shapes_dense_blocks_and_ragged_batch(D, zer
     assert np.isfinite(ca).all() and cases.rel_err(ca, cb) < 1e-12 and cases.rel_err(ka, kb) < 1e-12
     assert torch.equal(a._sgn, b._sgn)
     assert cases.rel_err(cnp(a._c2), cnp(b._c2)) < 1e-10 and cases.rel_err(cnp(a.y), cnp(b.y)) < 1e-13
+
+
+def test_whole_loop_in_normal_mode_coordinates_equals_the_product_with_phi():
+    """sc_hk_run_modal (round 4): run() of a constant dense Hessian with the monodromy blocks in normal-mode coordinates (per-mode
+    2 x 2 step matrices, transformed prefactor constants, two changes of basis around the loop) against the same loop with the
+    product with Phi(dt): reference goldens through both, state and correlation functions to 1e-12, signs exact"""
+    from tests.engine_cases import engine_potential, engine_propagator
+    g = cases.load("hk_methylium")
+    pot = engine_potential(g)
+    nt, dt, E0 = int(g["nt"]), float(g["dt"]), float(g["E0"])
+    out = []
+    for frm in (16, 10 ** 9):
+        prop = engine_propagator(g)
+        prop.normal_modes_from = frm
+        c, k = prop.run(pot, dt, nt, E0)
+        prop.synchronize()
+        assert bool(prop.__dict__.get("_modal_cache")) == (frm == 16)
+        assert cases.rel_err(c, g["cauto"]) < TOL and cases.rel_err(k, g["kic"]) < TOL
+        assert cases.rel_err(cnp(prop.y), g[f"y_{nt}"]) < TOL
+        out.append((c, k, cnp(prop.y), cnp(prop._c2), cnp(prop._sgn)))
+    a, b = out
+    assert cases.rel_err(a[0], b[0]) < 1e-12 and cases.rel_err(a[1], b[1]) < 1e-12
+    assert cases.rel_err(a[2], b[2]) < 1e-12 and cases.rel_err(a[3], b[3]) < 1e-11
+    assert np.array_equal(a[4], b[4])
+    # fewer steps than normal_modes_from: the changes of basis would cost more than they save
+    short = engine_propagator(g)
+    short.run(pot, dt, 8, E0)
+    assert not short.__dict__.get("_modal_cache")
