@@ -315,6 +315,9 @@ int sc_hk_run(const sc_potential *pot, const sc_state *st, const sc_hk_consts *h
  * L1 A, L2 B, A^-1 R1, B^-1 R2 as the prefactor constants -- real, dense: diag = 0.  The CALLER transforms st->mono before the call and back
  * after it (HermanKlukPropagator.run does, with two batched products); (q, p, S), the correlation terms and the energy guard are
  * in the original coordinates as in sc_hk_run.  Per lane and step 8 D multiply-adds replace the 8 D^2 of the product with Phi. */
+/* mono[i][p] <- left[p] . mono[i][p] . right[p] for the four blocks p = qq, qp, pq, pp of every trajectory (left, right: [4][D][D],
+ * row-major state, D <= 16): the change of basis in front of and behind sc_hk_run_modal. */
+int sc_mono_similarity(const sc_state *st, const double *left, const double *right, void *stream);
 int sc_hk_run_modal_supported(const sc_potential *pot, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0);
 int sc_hk_run_modal(const sc_potential *pot, const sc_state *st, const sc_hk_consts *hk, const sc_overlap_consts *ovl_t0,
                     const sc_nac_consts *nc, const double *vi, const double *probi, const double *nacq, double mc_norm,

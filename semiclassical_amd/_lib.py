@@ -109,6 +109,7 @@ SIGNATURES = {
     "sc_hk_run": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), P(sc_overlap_consts), P(sc_nac_consts), c_double_p,
                             c_double_p, c_double_p, C.c_double, C.c_double, C.c_int32, c_double_p, c_double_p, c_double_p,
                             C.c_void_p]),
+    "sc_mono_similarity": (C.c_int, [P(sc_state), c_double_p, c_double_p, C.c_void_p]),
     "sc_hk_run_modal_supported": (C.c_int, [P(sc_potential), P(sc_hk_consts), P(sc_overlap_consts)]),
     "sc_hk_run_modal": (C.c_int, [P(sc_potential), P(sc_state), P(sc_hk_consts), P(sc_overlap_consts), P(sc_nac_consts), c_double_p,
                                   c_double_p, c_double_p, C.c_double, C.c_double, C.c_int32, c_double_p, c_double_p, c_double_p,

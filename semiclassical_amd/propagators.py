@@ -674,11 +674,12 @@ class HermanKlukPropagator(object):
 
     def _to_normal_modes(self, modal, forward):
         """monodromy blocks <-> normal-mode coordinates, in place: Mqq~ = A^-1 Mqq A, Mqp~ = A^-1 Mqp B, Mpq~ = B^-1 Mpq A, Mpp~ = B^-1 Mpp B"""
-        M = self._mono.view(self.ntraj, 4, self.dim, self.dim)
-        A, B, Ai, Bi = modal["A"], modal["B"], modal["Ainv"], modal["Binv"]
-        pairs = ((Ai, A), (Ai, B), (Bi, A), (Bi, B)) if forward else ((A, Ai), (A, Bi), (B, Ai), (B, Bi))
-        for p, (left, right) in enumerate(pairs):
-            M[:, p] = torch.matmul(left, torch.matmul(M[:, p], right))
+        if "stacks" not in modal:
+            A, B, Ai, Bi = modal["A"], modal["B"], modal["Ainv"], modal["Binv"]
+            modal["stacks"] = {True: (torch.stack((Ai, Ai, Bi, Bi)).contiguous(), torch.stack((A, B, A, B)).contiguous()),
+                               False: (torch.stack((A, A, B, B)).contiguous(), torch.stack((Ai, Bi, Ai, Bi)).contiguous())}
+        left, right = modal["stacks"][forward]
+        check(lib.sc_mono_similarity(self._state, ptr(left), ptr(right), self._stream()))
 
     def _run_whole_loop(self, desc, dt, nt, slots, potential=None):
         if desc.kind not in (_lib.SC_POT_MORSE, _lib.SC_POT_HARMONIC_SEP, _lib.SC_POT_EPS_MORSE):
