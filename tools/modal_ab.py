@@ -12,7 +12,9 @@ g = cases.load("hk_methylium")
 pot = engine_potential(g)
 G0 = cases.T(g["Gamma_0"])
 q0 = cases.T(g["q0"])
-n, nt, dt, E0 = 100000, 200, float(g["dt"]), float(g["E0"])
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+dt, E0 = float(g["dt"]), float(g["E0"])
 out = []
 for frm in (16, 10 ** 9):
     prop = PR.HermanKlukPropagator(G0, G0, device="cuda")
