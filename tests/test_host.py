@@ -209,3 +209,24 @@ def test_cursor_handover_is_fenced_in_the_source():
     assert "#if" not in code[:code.index("__syncthreads();")] and "#endif" not in code[:code.index("__syncthreads();")]
     # the two LDS words are defined before the first trajectory
     assert re.search(r"nextbuf\[tid\] = 0; weakbuf\[tid\] = 0;", src)
+
+
+def test_normal_mode_step_matrices_reproduce_the_full_step_matrix():
+    """MolecularHarmonicPotential._normal_modes (sc_hk_run_modal): T blockdiag-by-mode(phi) T^-1 with T = diag(A, B) is the RK4 step
+    matrix Phi(dt) of _step_matrix, including zero-frequency modes (free motion) and a wide mass ratio"""
+    from semiclassical_amd import potentials as P
+    rng = np.random.default_rng(7)
+    D, dt = 12, 0.8
+    masses = rng.uniform(1800.0, 2.2e4, D)
+    W = rng.standard_normal((D, D - 6))
+    H = (W @ W.T) * 0.05                                  # rank D - 6: six zero modes, as for a molecule in Cartesian coordinates
+    H = H * np.sqrt(np.outer(masses, masses)) / 1.0e4
+    pot = P.MolecularHarmonicPotential.from_arrays(np.zeros(D), np.float64(0.0), np.zeros(D), H, masses, np.zeros(D))
+    A, B, Ainv, Binv, phi = pot._normal_modes(dt)
+    assert np.max(np.abs(Ainv @ A - np.eye(D))) < 1e-12 and np.max(np.abs(Binv @ B - np.eye(D))) < 1e-12
+    assert np.max(np.abs(B.T @ A - np.eye(D))) < 1e-12   # what makes G = Mp'^T Mq' invariant (DESIGN section 7)
+    T = np.block([[A, np.zeros((D, D))], [np.zeros((D, D)), B]])
+    Ti = np.block([[Ainv, np.zeros((D, D))], [np.zeros((D, D)), Binv]])
+    mid = np.block([[np.diag(phi[:, 0]), np.diag(phi[:, 1])], [np.diag(phi[:, 2]), np.diag(phi[:, 3])]])
+    full = pot._step_matrix(dt)
+    assert np.max(np.abs(T @ mid @ Ti - full)) < 1e-12 * np.max(np.abs(full))
