@@ -117,6 +117,40 @@ def test_harmonic_task_matches_reference_driver(prop, tol, tmp_path, monkeypatch
     assert str(got["broadening"]) == str(ref["broadening"]) and float(got["hwhmG"]) == float(ref["hwhmG"])
 
 
+def test_anharmonic_as60_task_matches_reference_driver(tmp_path, monkeypatch):
+    """BASELINE.json config 2's model family through the PRODUCT driver: an "anharmonic AS" task with the synthetic 60-mode model
+    (model file in the reference's four-column format), HK, two repetitions of 48 trajectories, 24 steps -- against the npz the
+    REFERENCE's run_semiclassical_dynamics + calculate_rates wrote for the same sampled initial conditions
+    (tests/golden/driver_as60.npz, make_golden_driver_round4.py; cli.py:171-476, 519-570).  run() takes two time steps per launch
+    here (16 < D <= 64)."""
+    from semiclassical_amd import driver, propagators as PR
+    g = cases.load("driver_as60")
+    task = json.loads(str(g["task"]))
+    model = tmp_path / "AS_model_60.dat"
+    np.savetxt(model, g["model_rows"])
+    out = tmp_path / "correlations.npz"
+    task["potential"] = {"type": "anharmonic AS", "model_file": str(model)}
+    task["results"] = {"correlations": str(out)}
+    count = _inject_initial_conditions(monkeypatch, g["zi"], g["probi"])
+    seen = []
+    pair = PR.HermanKlukPropagator._launch_step_pair
+    monkeypatch.setattr(PR.HermanKlukPropagator, "_launch_step_pair", lambda self, *a, **k: (seen.append(1), pair(self, *a, **k))[1])
+    driver.run_semiclassical_dynamics(task, device="cuda")
+    assert count["rep"] == 2 and len(seen) == 2 * 12                  # 24 steps in pairs, twice
+    driver.calculate_rates(dict(json.loads(str(g["rates_task"])), correlations=str(out), rates=str(out)))
+    got = dict(np.load(out))
+    ref = {k[4:]: v for k, v in g.items() if k.startswith("res_")}
+    assert set(got) == set(ref), set(got) ^ set(ref)
+    assert int(got["trajectories"]) == int(ref["trajectories"]) == 96 and np.array_equal(got["times"], ref["times"])
+    assert abs(float(got["zero_point_energy"]) - float(ref["zero_point_energy"])) < 1e-12
+    assert np.isnan(float(got["adiabatic_gap"])) and np.isnan(float(ref["adiabatic_gap"]))      # not defined for model potentials
+    e_c, e_k = cases.rel_err(got["autocorrelation"], ref["autocorrelation"]), cases.rel_err(got["ic_correlation"], ref["ic_correlation"])
+    e_r = cases.rel_err(got["ic_rate"], ref["ic_rate"])
+    print(f"driver task AS60: achieved deviation from the reference's npz  C(t) {e_c:.2e}  k_ic(t) {e_k:.2e}  ic_rate {e_r:.2e}")
+    assert e_c < 1e-10 and e_k < 1e-10 and e_r < 1e-10
+    assert np.array_equal(got["energies"], ref["energies"])
+
+
 def test_gdml_task_runs_through_the_driver(tmp_path):
     """'gdml' potential type (cli.py:204-227) on the coumarin model.  The reference itself does not get through this
     task: its Newton / Armijo minimisation from the S1 geometry solves with a Hessian that has six zero modes and
