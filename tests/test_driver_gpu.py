@@ -151,6 +151,30 @@ def test_anharmonic_as60_task_matches_reference_driver(tmp_path, monkeypatch):
     assert np.array_equal(got["energies"], ref["energies"])
 
 
+def test_anharmonic_as24_wm_task_matches_reference_driver(tmp_path, monkeypatch):
+    """the same with the Walton-Manolopoulos propagator on the first 24 modes (D > 16: the LDS WM kernel), cell_width 500:
+    tests/golden/driver_as24_wm.npz"""
+    from semiclassical_amd import driver
+    g = cases.load("driver_as24_wm")
+    task = json.loads(str(g["task"]))
+    model = tmp_path / "AS_model_24.dat"
+    np.savetxt(model, g["model_rows"])
+    out = tmp_path / "correlations.npz"
+    task["potential"] = {"type": "anharmonic AS", "model_file": str(model)}
+    task["results"] = {"correlations": str(out)}
+    count = _inject_initial_conditions(monkeypatch, g["zi"], g["probi"])
+    driver.run_semiclassical_dynamics(task, device="cuda")
+    assert count["rep"] == 2
+    driver.calculate_rates(dict(json.loads(str(g["rates_task"])), correlations=str(out), rates=str(out)))
+    got = dict(np.load(out))
+    ref = {k[4:]: v for k, v in g.items() if k.startswith("res_")}
+    assert set(got) == set(ref) and str(got["propagator"]) == "WM" and int(got["trajectories"]) == 48
+    e_c, e_k = cases.rel_err(got["autocorrelation"], ref["autocorrelation"]), cases.rel_err(got["ic_correlation"], ref["ic_correlation"])
+    e_r = cases.rel_err(got["ic_rate"], ref["ic_rate"])
+    print(f"driver task AS24 WM: achieved deviation from the reference's npz  C(t) {e_c:.2e}  k_ic(t) {e_k:.2e}  ic_rate {e_r:.2e}")
+    assert e_c < 1e-9 and e_k < 1e-9 and e_r < 1e-9
+
+
 def test_gdml_task_runs_through_the_driver(tmp_path):
     """'gdml' potential type (cli.py:204-227) on the coumarin model.  The reference itself does not get through this
     task: its Newton / Armijo minimisation from the S1 geometry solves with a Hessian that has six zero modes and
